@@ -1,0 +1,187 @@
+/*
+ * pvq.h — C ABI of libpvq: MI355X-native batched VQT pitch-analysis engine.
+ *
+ * Drop-in boundary for the hot path of heinzelotto/pitchvis' `pitchvis_analysis` crate.  The
+ * reference has no FFI of its own (consumers link the rlib); every entry point
+ * below names the Rust item it replaces (paths relative to pitchvis_analysis/src/).  A Rust shim
+ * that re-exposes `Vqt` / `VqtParameters` / `VqtError` over these symbols is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, caller-allocated outputs, no exceptions cross the ABI,
+ * every fallible call returns a pvq_status.  A handle is NOT thread-safe (the reference takes
+ * `&mut self`, vqt.rs:866); distinct handles are independent (one per worker thread / stream,
+ * as pitchvis_train/src/train.rs:146-155 does).  All compute runs on the GPU: there is no CPU
+ * fallback, and every compute entry point fails with PVQ_ERR_NO_DEVICE on a handle created
+ * without a device.
+ */
+#ifndef PVQ_H
+#define PVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVQ_ABI_VERSION 1
+
+/* replaces VqtParameters + VqtRange (vqt.rs:238-262, 278-331), flattened POD */
+typedef struct pvq_vqt_params {
+    float sr;                    /* VqtParameters::sr */
+    uint32_t n_fft;              /* VqtParameters::n_fft */
+    float min_freq;              /* VqtRange::min_freq */
+    uint32_t octaves;            /* VqtRange::octaves (u8 in the reference) */
+    uint32_t buckets_per_octave; /* VqtRange::buckets_per_octave (u16 in the reference) */
+    float sparsity_quantile;     /* VqtParameters::sparsity_quantile */
+    float quality;               /* VqtParameters::quality */
+    float gamma;                 /* VqtParameters::gamma */
+} pvq_vqt_params;
+
+/* replaces VqtError (vqt.rs:350-366) plus the panics of vqt.rs:867-871 / analysis.rs:289 */
+typedef enum pvq_status {
+    PVQ_OK = 0,
+    PVQ_ERR_ABOVE_NYQUIST = 1,        /* VqtError::AboveNyquist{highest_frequency, nyquist_frequency} */
+    PVQ_ERR_WINDOW_EXCEEDS_NFFT = 2,  /* VqtError::WindowExceedsNFft{window_length, n_fft} */
+    PVQ_ERR_BAD_LENGTH = 3,           /* assert_eq!(x.len(), n_fft) vqt.rs:867-871 */
+    PVQ_ERR_INVALID_ARG = 4,
+    PVQ_ERR_NO_DEVICE = 5,            /* handle has no GPU context (created with device_id < 0) */
+    PVQ_ERR_DEVICE = 6,               /* a HIP call failed; see pvq_last_error() */
+    PVQ_ERR_UNSUPPORTED = 7           /* geometry outside what the kernels support */
+} pvq_status;
+
+const char *pvq_status_string(pvq_status s);
+/* thread-local text of the last failing call on this thread */
+const char *pvq_last_error(void);
+uint32_t pvq_abi_version(void);
+
+/* replaces `impl Default for VqtParameters` (vqt.rs:333-348) and DEFAULT_* (vqt.rs:180-214) */
+void pvq_vqt_default_params(pvq_vqt_params *p);
+
+typedef struct pvq_vqt pvq_vqt;
+
+/*
+ * replaces Vqt::new (vqt.rs:465-505).  Builds the multi-rate sparse kernel on the host
+ * (vqt.rs:517-852) and, when device_id >= 0, uploads it to that GPU.  device_id < 0 creates a
+ * host-only "plan" handle: getters work, compute entry points return PVQ_ERR_NO_DEVICE.
+ * On PVQ_ERR_ABOVE_NYQUIST / PVQ_ERR_WINDOW_EXCEEDS_NFFT err_detail receives the two fields of
+ * the corresponding VqtError variant.
+ */
+pvq_status pvq_vqt_create(const pvq_vqt_params *params, int device_id, pvq_vqt **out,
+                          float err_detail[2]);
+/* replaces Drop for Vqt (the viewer swaps the instance at runtime, pitchvis_viewer/src/app/common.rs:1133) */
+void pvq_vqt_destroy(pvq_vqt *v);
+
+/* replaces Vqt::params() (vqt.rs:507-509) */
+void pvq_vqt_get_params(const pvq_vqt *v, pvq_vqt_params *out);
+/* replaces VqtRange::n_buckets() (vqt.rs:259-261) */
+uint32_t pvq_vqt_n_bins(const pvq_vqt *v);
+/* replaces `pub delay: Duration` (vqt.rs:449, :756), in seconds */
+double pvq_vqt_delay_seconds(const pvq_vqt *v);
+/* number of trailing samples of the n_fft buffer that any window group reads (the window union) */
+uint32_t pvq_vqt_window_union(const pvq_vqt *v);
+
+/* replaces Vqt::kernel() (vqt.rs:511-513) -> VqtKernel{window_groups} (vqt.rs:388-415) */
+uint32_t pvq_vqt_n_groups(const pvq_vqt *v);
+/* info[0]=window.0, [1]=window.1, [2]=filter_bank.rows(), [3]=filter_bank.nnz(),
+ * [4]=negative_filter_bank nnz (0 <=> None) */
+pvq_status pvq_vqt_group_info(const pvq_vqt *v, uint32_t group, uint32_t info[5]);
+/* CSR copy-out of WindowGroup::filter_bank (negative=0) or ::negative_filter_bank (negative=1);
+ * values are interleaved (re, im) Complex32 */
+pvq_status pvq_vqt_group_csr(const pvq_vqt *v, uint32_t group, int negative, uint32_t *row_ptr,
+                             uint32_t *col_idx, float *values);
+/* per-bin FilterParams (vqt.rs:370-384), arrays of n_bins */
+pvq_status pvq_vqt_filter_params(const pvq_vqt *v, float *freq, float *window_length,
+                                 uint32_t *sr_downscaling_factor, uint32_t *minimum_needed_window_size);
+
+/*
+ * replaces Vqt::calculate_vqt_instant_in_db (vqt.rs:866-916): x = exactly n_fft host samples,
+ * the last of which is "now"; out_db = n_bins host floats.  len != n_fft -> PVQ_ERR_BAD_LENGTH
+ * (the reference panics).  Synchronous.
+ */
+pvq_status pvq_vqt_calculate_instant_db(pvq_vqt *v, const float *x, size_t len, float *out_db);
+
+/*
+ * Batched form of the same call, the data-parallel path the reference runs with one Vqt per
+ * rayon worker (pitchvis_train/src/train.rs:146-155, :276-310, :341).
+ * Framing: a ring buffer of n_fft zeros; hop f (0-based) shifts `hop` samples in, then frame f
+ * analyses the last n_fft samples (pitchvis_audio/src/audio_desktop.rs:113-115 shift semantics).
+ * `pcm` holds n_lead + n_frames*hop samples; the first n_lead are history that precedes hop 0
+ * (0 at stream start, > 0 for a shard that carries a halo); samples before pcm[0] are zeros.
+ * out_db: [n_frames][n_bins] row-major.  Host pointers; synchronous.
+ */
+pvq_status pvq_vqt_calculate_batch_db(pvq_vqt *v, const float *pcm, size_t n_lead, size_t hop,
+                                      size_t n_frames, float *out_db);
+
+/*
+ * Device-pointer form: d_pcm, d_out_db (and optional d_out_cplx: [n_frames][n_bins][2], the
+ * complex coefficients before power_to_db, may be NULL) are device memory on the handle's GPU.
+ * Enqueued on `stream` (a hipStream_t; NULL = default stream); returns without synchronising.
+ */
+pvq_status pvq_vqt_calculate_batch_db_device(pvq_vqt *v, const float *d_pcm, size_t n_lead,
+                                             size_t hop, size_t n_frames, float *d_out_db,
+                                             float *d_out_cplx, void *stream);
+
+/* algorithm selection for the batch path (default PVQ_ALGO_AUTO) */
+typedef enum pvq_algo {
+    PVQ_ALGO_AUTO = 0,
+    PVQ_ALGO_FFT = 1,      /* per-frame LDS FFT per window group (any hop) */
+    PVQ_ALGO_BLOCKDFT = 2  /* hop-block DFT on fp32 MFMA + phase combine (power-of-two hop dividing every window) */
+} pvq_algo;
+pvq_status pvq_vqt_set_algo(pvq_vqt *v, pvq_algo algo);
+/* which algorithm the last batch call actually used */
+pvq_algo pvq_vqt_last_algo(const pvq_vqt *v);
+
+/* ---- peak / note detection: analysis_modules/peak_detection.rs + analysis.rs:332-361 ---- */
+
+/* replaces the peak-related fields of AnalysisParameters (analysis.rs:36-65, defaults :72-98) */
+typedef struct pvq_analysis_params {
+    float peak_min_prominence;     /* peak_config.min_prominence = 10.0 */
+    float peak_min_height;         /* peak_config.min_height = 4.0 */
+    float bass_min_prominence;     /* bassline_peak_config.min_prominence = 5.0 */
+    float bass_min_height;         /* bassline_peak_config.min_height = 3.5 */
+    uint32_t highest_bassnote;     /* 28 */
+    float harmonic_threshold;      /* 0.3 */
+} pvq_analysis_params;
+void pvq_analysis_default_params(pvq_analysis_params *a);
+
+/*
+ * Per-frame stateless analysis of dB frames, i.e. AnalysisState::preprocess's peak pipeline
+ * (analysis.rs:332-361: find_peaks bass/general split -> enhance_peaks_continuous ->
+ * promote_bass_peaks_with_harmonics) with the EMA in pass-through mode
+ * (update_vqt_smoothing_duration(None), analysis.rs:251-269).
+ * d_db: [n_frames][n_bins] device.  Outputs (device, any may be NULL):
+ *   d_peak_mask  [n_frames][ceil(n_bins/32)] u32 bitmask of AnalysisState::peaks
+ *   d_peak_count [n_frames] number of peaks
+ *   d_center/d_size [n_frames][max_peaks] AnalysisState::peaks_continuous, ascending center;
+ *                   entries beyond the frame's count are untouched.
+ */
+pvq_status pvq_analyze_batch_device(pvq_vqt *v, const float *d_db, size_t n_frames,
+                                    const pvq_analysis_params *a, uint32_t *d_peak_mask,
+                                    uint32_t *d_peak_count, float *d_center, float *d_size,
+                                    uint32_t max_peaks, void *stream);
+
+/* Host-pointer convenience wrapper of the above (uploads, runs on the GPU, downloads). */
+pvq_status pvq_analyze_batch(pvq_vqt *v, const float *db, size_t n_frames,
+                             const pvq_analysis_params *a, uint32_t *peak_mask, uint32_t *peak_count,
+                             float *center, float *size, uint32_t max_peaks);
+
+/* The whole hot path in one call: PCM -> VQT dB frames -> peaks (device pointers, async). */
+pvq_status pvq_vqt_analyze_batch_device(pvq_vqt *v, const float *d_pcm, size_t n_lead, size_t hop,
+                                        size_t n_frames, const pvq_analysis_params *a,
+                                        float *d_out_db, uint32_t *d_peak_mask,
+                                        uint32_t *d_peak_count, float *d_center, float *d_size,
+                                        uint32_t max_peaks, void *stream);
+
+/* timing hook for bench.py: elapsed GPU milliseconds of the dominant kernel launches of the
+ * last batch call, measured with HIP events on the stream the kernels were launched on.
+ * Enable with pvq_vqt_set_profiling(v, 1); reading synchronises the stream. */
+pvq_status pvq_vqt_set_profiling(pvq_vqt *v, int enable);
+/* out_ms[i] for kernel slot i (see pvq_vqt_kernel_name); returns the number of slots filled */
+uint32_t pvq_vqt_last_kernel_ms(pvq_vqt *v, float *out_ms, uint32_t capacity);
+const char *pvq_vqt_kernel_name(uint32_t slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVQ_H */

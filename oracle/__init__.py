@@ -168,9 +168,12 @@ class OracleVqt:
         self.window_center = lib().orc_window_center(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().orc_vqt_free(self._h)
-            self._h = C.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().orc_vqt_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def filter_params(self):
         n = self.n_bins

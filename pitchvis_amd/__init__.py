@@ -1,0 +1,355 @@
+"""pitchvis_amd — MI355X-native batched VQT pitch-analysis engine (Python face of libpvq).
+
+Mirrors the public surface of the reference crate `pitchvis_analysis` for its hot path
+(reference files pitchvis_analysis/src/vqt.rs, analysis.rs, analysis_modules/peak_detection.rs):
+
+    VqtRange, VqtParameters, VqtError{AboveNyquist, WindowExceedsNFft}, WindowGroup, VqtKernel,
+    Vqt.new / params() / kernel() / delay / calculate_vqt_instant_in_db,
+    PeakDetectionParameters, AnalysisParameters, ContinuousPeak
+
+plus the batched forms the GPU makes worthwhile.  Everything computes on the GPU through the
+C ABI in include/pvq.h; there is no CPU fallback (a handle without a device refuses to compute).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALGO_AUTO, ALGO_BLOCKDFT, ALGO_FFT  # noqa: F401
+
+__all__ = [
+    "VqtRange", "VqtParameters", "VqtError", "AboveNyquist", "WindowExceedsNFft", "PvqError", "WindowGroup",
+    "VqtKernel", "Vqt", "PeakDetectionParameters", "AnalysisParameters", "ContinuousPeak", "FrameAnalysis",
+    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT",
+]
+
+
+# ---- vqt.rs:238-262 -------------------------------------------------------------------------
+@dataclass
+class VqtRange:
+    min_freq: float = 55.0
+    octaves: int = 7
+    buckets_per_octave: int = 84
+
+    def n_buckets(self) -> int:
+        return self.buckets_per_octave * self.octaves
+
+
+# ---- vqt.rs:278-348 -------------------------------------------------------------------------
+@dataclass
+class VqtParameters:
+    sr: float = 22050.0
+    n_fft: int = 2 * 16384
+    range: VqtRange = field(default_factory=VqtRange)
+    sparsity_quantile: float = 0.999
+    quality: float = 1.6
+    gamma: float = 4.8 * 1.6
+
+    @staticmethod
+    def default() -> "VqtParameters":
+        p = _lib.CParams()
+        _lib.load().pvq_vqt_default_params(C.byref(p))
+        return VqtParameters(p.sr, p.n_fft, VqtRange(p.min_freq, p.octaves, p.buckets_per_octave),
+                             p.sparsity_quantile, p.quality, p.gamma)
+
+    def _c(self) -> _lib.CParams:
+        return _lib.CParams(self.sr, self.n_fft, self.range.min_freq, self.range.octaves,
+                            self.range.buckets_per_octave, self.sparsity_quantile, self.quality, self.gamma)
+
+
+# ---- vqt.rs:350-366 -------------------------------------------------------------------------
+class PvqError(RuntimeError):
+    """Any non-OK pvq_status that is not a VqtError variant."""
+
+    def __init__(self, status: int, msg: str):
+        self.status = status
+        super().__init__(f"pvq status {status}: {msg}")
+
+
+class VqtError(Exception):
+    pass
+
+
+class AboveNyquist(VqtError):
+    def __init__(self, highest_frequency: float, nyquist_frequency: float):
+        self.highest_frequency, self.nyquist_frequency = highest_frequency, nyquist_frequency
+        super().__init__(f"the highest VQT bin frequency ({highest_frequency} Hz) exceeds the Nyquist frequency "
+                         f"({nyquist_frequency} Hz); reduce octaves or increase the sample rate")
+
+
+class WindowExceedsNFft(VqtError):
+    def __init__(self, window_length: float, n_fft: int):
+        self.window_length, self.n_fft = window_length, n_fft
+        super().__init__(f"the longest filter window ({window_length} samples) exceeds n_fft ({n_fft} samples); "
+                         "increase n_fft or gamma, or decrease quality")
+
+
+def _check(st: int):
+    if st != _lib.PVQ_OK:
+        L = _lib.load()
+        raise PvqError(st, f"{L.pvq_status_string(st).decode()}: {L.pvq_last_error().decode()}")
+
+
+# ---- vqt.rs:388-415 -------------------------------------------------------------------------
+@dataclass
+class CsMat:
+    """sprs::CsMat<Complex32> as CSR arrays."""
+    shape: tuple
+    indptr: np.ndarray
+    indices: np.ndarray
+    data: np.ndarray  # complex64
+
+    def nnz(self) -> int:
+        return int(self.indices.size)
+
+    def rows(self) -> int:
+        return self.shape[0]
+
+    def to_dense(self) -> np.ndarray:
+        d = np.zeros(self.shape, np.complex64)
+        for r in range(self.shape[0]):
+            s, e = self.indptr[r], self.indptr[r + 1]
+            d[r, self.indices[s:e]] = self.data[s:e]
+        return d
+
+
+@dataclass
+class WindowGroup:
+    window: tuple
+    filter_bank: CsMat
+    negative_filter_bank: Optional[CsMat]
+
+    def window_size(self) -> int:
+        return self.window[1] - self.window[0]
+
+
+@dataclass
+class VqtKernel:
+    window_groups: List[WindowGroup]
+
+
+# ---- analysis_modules/peak_detection.rs:9-23, analysis.rs:36-98 --------------------------------
+@dataclass
+class PeakDetectionParameters:
+    min_prominence: float
+    min_height: float
+
+
+@dataclass
+class AnalysisParameters:
+    peak_config: PeakDetectionParameters = field(default_factory=lambda: PeakDetectionParameters(10.0, 4.0))
+    bassline_peak_config: PeakDetectionParameters = field(default_factory=lambda: PeakDetectionParameters(5.0, 3.5))
+    highest_bassnote: int = 12 * 2 + 4
+    harmonic_threshold: float = 0.3
+
+    def _c(self) -> _lib.CAnalysisParams:
+        return _lib.CAnalysisParams(self.peak_config.min_prominence, self.peak_config.min_height,
+                                    self.bassline_peak_config.min_prominence, self.bassline_peak_config.min_height,
+                                    self.highest_bassnote, self.harmonic_threshold)
+
+
+@dataclass
+class ContinuousPeak:
+    center: float
+    size: float
+
+
+@dataclass
+class FrameAnalysis:
+    """Per-frame result of the stateless peak pipeline (AnalysisState::peaks, ::peaks_continuous)."""
+    peaks: set
+    peaks_continuous: List[ContinuousPeak]
+
+
+def _ptr(t) -> int:
+    """device pointer of a torch tensor (or a raw int)"""
+    if t is None:
+        return 0
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def _stream_handle(stream) -> int:
+    if stream is None:
+        try:
+            import torch
+            return torch.cuda.current_stream().cuda_stream
+        except Exception:
+            return 0
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream
+
+
+class Vqt:
+    """GPU-backed mirror of pitchvis_analysis::vqt::Vqt (vqt.rs:440-513, :866-916).
+
+    `device=None` builds a host-only plan (getters work; compute raises: no CPU fallback).
+    """
+
+    def __init__(self, params: VqtParameters, device: Optional[int] = 0):
+        L = _lib.load()
+        self._L = L
+        self._params = params
+        self._h = C.c_void_p()
+        err = (C.c_float * 2)()
+        cp = params._c()
+        st = L.pvq_vqt_create(C.byref(cp), -1 if device is None else int(device), C.byref(self._h), err)
+        if st == _lib.PVQ_ERR_ABOVE_NYQUIST:
+            raise AboveNyquist(err[0], err[1])
+        if st == _lib.PVQ_ERR_WINDOW_EXCEEDS_NFFT:
+            raise WindowExceedsNFft(err[0], int(err[1]))
+        _check(st)
+        self.device = device
+        self.n_bins = L.pvq_vqt_n_bins(self._h)
+        #: vqt.rs:449 `pub delay: Duration`, in seconds
+        self.delay = L.pvq_vqt_delay_seconds(self._h)
+        self.window_union = L.pvq_vqt_window_union(self._h)
+
+    @classmethod
+    def new(cls, params: VqtParameters, device: Optional[int] = 0) -> "Vqt":
+        return cls(params, device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        try:
+            if h is not None and h.value:
+                self._L.pvq_vqt_destroy(h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+    # vqt.rs:507-513
+    def params(self) -> VqtParameters:
+        return self._params
+
+    def kernel(self) -> VqtKernel:
+        L = self._L
+        groups = []
+        for g in range(L.pvq_vqt_n_groups(self._h)):
+            info = (C.c_uint32 * 5)()
+            _check(L.pvq_vqt_group_info(self._h, g, info))
+            w0, w1, rows, nnz, nneg = [int(v) for v in info]
+            mats = []
+            for neg, n in ((0, nnz), (1, nneg)):
+                rp = np.zeros(rows + 1, np.uint32)
+                ci = np.zeros(max(n, 1), np.uint32)
+                va = np.zeros(2 * max(n, 1), np.float32)
+                _check(L.pvq_vqt_group_csr(self._h, g, neg, rp.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                           ci.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                           va.ctypes.data_as(C.POINTER(C.c_float))))
+                mats.append(CsMat((rows, (w1 - w0) // 2 + 1), rp, ci[:n], va[: 2 * n].view(np.complex64)))
+            groups.append(WindowGroup((w0, w1), mats[0], mats[1] if nneg > 0 else None))
+        return VqtKernel(groups)
+
+    def filter_params(self):
+        n = self.n_bins
+        freq = np.empty(n, np.float32); wl = np.empty(n, np.float32)
+        m = np.empty(n, np.uint32); mw = np.empty(n, np.uint32)
+        _check(self._L.pvq_vqt_filter_params(self._h, freq.ctypes.data_as(C.POINTER(C.c_float)),
+                                             wl.ctypes.data_as(C.POINTER(C.c_float)),
+                                             m.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             mw.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return freq, wl, m, mw
+
+    # ---- compute -----------------------------------------------------------------------------
+    def calculate_vqt_instant_in_db(self, x) -> np.ndarray:
+        """vqt.rs:866: x = exactly n_fft samples, the last of which is "now"."""
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 1 or x.size != self._params.n_fft:
+            # the reference panics with this message (vqt.rs:867-871)
+            raise AssertionError("input must be exactly n_fft samples")
+        out = np.empty(self.n_bins, np.float32)
+        _check(self._L.pvq_vqt_calculate_instant_db(self._h, x.ctypes.data_as(C.POINTER(C.c_float)), x.size,
+                                                    out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def calculate_batch_db(self, pcm, hop: int, n_frames: Optional[int] = None, n_lead: int = 0) -> np.ndarray:
+        """Host arrays in/out.  Frame f analyses the last n_fft samples after hop f (zeros before
+        the stream start); pcm holds n_lead + n_frames*hop samples."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if n_frames is None:
+            n_frames = (pcm.size - n_lead) // hop
+        if pcm.size < n_lead + n_frames * hop:
+            raise ValueError("pcm shorter than n_lead + n_frames*hop")
+        out = np.empty((n_frames, self.n_bins), np.float32)
+        if n_frames:
+            _check(self._L.pvq_vqt_calculate_batch_db(self._h, pcm.ctypes.data_as(C.POINTER(C.c_float)), n_lead, hop,
+                                                      n_frames, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def calculate_batch_db_device(self, d_pcm, hop: int, n_frames: int, d_out_db, n_lead: int = 0,
+                                  d_out_cplx=None, stream=None) -> None:
+        """torch CUDA tensors (or raw device pointers); asynchronous on `stream`."""
+        _check(self._L.pvq_vqt_calculate_batch_db_device(self._h, _ptr(d_pcm), n_lead, hop, n_frames, _ptr(d_out_db),
+                                                         _ptr(d_out_cplx), _stream_handle(stream)))
+
+    def analyze_batch_device(self, d_db, n_frames: int, d_peak_mask=None, d_peak_count=None, d_center=None,
+                             d_size=None, max_peaks: int = 0, analysis: Optional[AnalysisParameters] = None,
+                             stream=None) -> None:
+        ap = (analysis or AnalysisParameters())._c()
+        _check(self._L.pvq_analyze_batch_device(self._h, _ptr(d_db), n_frames, C.byref(ap), _ptr(d_peak_mask),
+                                                _ptr(d_peak_count), _ptr(d_center), _ptr(d_size), max_peaks,
+                                                _stream_handle(stream)))
+
+    def vqt_analyze_batch_device(self, d_pcm, hop: int, n_frames: int, d_out_db, d_peak_mask=None, d_peak_count=None,
+                                 d_center=None, d_size=None, max_peaks: int = 0, n_lead: int = 0,
+                                 analysis: Optional[AnalysisParameters] = None, stream=None) -> None:
+        """The whole hot path: PCM -> dB frames -> peaks, asynchronous on `stream`."""
+        ap = (analysis or AnalysisParameters())._c()
+        _check(self._L.pvq_vqt_analyze_batch_device(self._h, _ptr(d_pcm), n_lead, hop, n_frames, C.byref(ap),
+                                                    _ptr(d_out_db), _ptr(d_peak_mask), _ptr(d_peak_count),
+                                                    _ptr(d_center), _ptr(d_size), max_peaks, _stream_handle(stream)))
+
+    def analyze_batch(self, db, analysis: Optional[AnalysisParameters] = None, max_peaks: int = 64):
+        """Host dB frames [n_frames][n_bins] -> (mask u32 [n_frames][words], count, center, size)."""
+        db = np.ascontiguousarray(db, np.float32)
+        if db.ndim == 1:
+            db = db[None, :]
+        if db.shape[1] != self.n_bins:
+            raise AssertionError("x_vqt.len() == range.n_buckets()")  # analysis.rs:289
+        n = db.shape[0]
+        words = (self.n_bins + 31) // 32
+        mask = np.zeros((n, words), np.uint32)
+        count = np.zeros(n, np.uint32)
+        center = np.zeros((n, max_peaks), np.float32)
+        size = np.zeros((n, max_peaks), np.float32)
+        ap = (analysis or AnalysisParameters())._c()
+        if n:
+            _check(self._L.pvq_analyze_batch(self._h, db.ctypes.data_as(C.POINTER(C.c_float)), n, C.byref(ap),
+                                             mask.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             count.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             center.ctypes.data_as(C.POINTER(C.c_float)),
+                                             size.ctypes.data_as(C.POINTER(C.c_float)), max_peaks))
+        return mask, count, center, size
+
+    def analyze_frames(self, db, analysis: Optional[AnalysisParameters] = None, max_peaks: int = 64) -> List[FrameAnalysis]:
+        """AnalysisState::preprocess's peak outputs per frame, smoothing disabled (analysis.rs:332-361)."""
+        mask, count, center, size = self.analyze_batch(db, analysis, max_peaks)
+        out = []
+        for f in range(mask.shape[0]):
+            bits = np.unpackbits(mask[f].view(np.uint8), bitorder="little")[: self.n_bins]
+            peaks = set(int(i) for i in np.nonzero(bits)[0])
+            k = min(int(count[f]), max_peaks)
+            out.append(FrameAnalysis(peaks, [ContinuousPeak(float(center[f, j]), float(size[f, j])) for j in range(k)]))
+        return out
+
+    # ---- knobs ---------------------------------------------------------------------------------
+    def set_algo(self, algo: int) -> None:
+        _check(self._L.pvq_vqt_set_algo(self._h, algo))
+
+    def last_algo(self) -> int:
+        return self._L.pvq_vqt_last_algo(self._h)
+
+    def set_profiling(self, on: bool) -> None:
+        _check(self._L.pvq_vqt_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self) -> dict:
+        buf = (C.c_float * 8)()
+        n = self._L.pvq_vqt_last_kernel_ms(self._h, buf, 8)
+        return {self._L.pvq_vqt_kernel_name(i).decode(): buf[i] for i in range(n) if buf[i] >= 0.0}

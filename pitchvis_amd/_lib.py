@@ -1,0 +1,115 @@
+"""ctypes binding of libpvq.so (include/pvq.h).  Fails loudly if the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpvq.so")
+
+# every symbol include/pvq.h declares
+EXPORTS = [
+    "pvq_status_string", "pvq_last_error", "pvq_abi_version", "pvq_vqt_default_params", "pvq_vqt_create",
+    "pvq_vqt_destroy", "pvq_vqt_get_params", "pvq_vqt_n_bins", "pvq_vqt_delay_seconds", "pvq_vqt_window_union",
+    "pvq_vqt_n_groups", "pvq_vqt_group_info", "pvq_vqt_group_csr", "pvq_vqt_filter_params",
+    "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
+    "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
+    "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
+    "pvq_vqt_kernel_name",
+]
+
+PVQ_OK = 0
+PVQ_ERR_ABOVE_NYQUIST = 1
+PVQ_ERR_WINDOW_EXCEEDS_NFFT = 2
+PVQ_ERR_BAD_LENGTH = 3
+PVQ_ERR_INVALID_ARG = 4
+PVQ_ERR_NO_DEVICE = 5
+PVQ_ERR_DEVICE = 6
+PVQ_ERR_UNSUPPORTED = 7
+
+ALGO_AUTO, ALGO_FFT, ALGO_BLOCKDFT = 0, 1, 2
+
+
+class CParams(C.Structure):
+    _fields_ = [
+        ("sr", C.c_float),
+        ("n_fft", C.c_uint32),
+        ("min_freq", C.c_float),
+        ("octaves", C.c_uint32),
+        ("buckets_per_octave", C.c_uint32),
+        ("sparsity_quantile", C.c_float),
+        ("quality", C.c_float),
+        ("gamma", C.c_float),
+    ]
+
+
+class CAnalysisParams(C.Structure):
+    _fields_ = [
+        ("peak_min_prominence", C.c_float),
+        ("peak_min_height", C.c_float),
+        ("bass_min_prominence", C.c_float),
+        ("bass_min_height", C.c_float),
+        ("highest_bassnote", C.c_uint32),
+        ("harmonic_threshold", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libpvq.so; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C pitchvis_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`).  pitchvis_amd has no CPU fallback."
+        )
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Both HIP
+    # runtimes in one process do not coexist (whichever initialises second sees no GPU), and the
+    # dynamic loader de-duplicates by SONAME, so: let torch's copy load first whenever torch is
+    # installed; libpvq then binds to that same runtime.  Without torch the system ROCm runtime
+    # is used.  (torch is plumbing here: device memory, streams, torch.distributed.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+    L.pvq_status_string.argtypes = [C.c_int]; L.pvq_status_string.restype = C.c_char_p
+    L.pvq_last_error.argtypes = []; L.pvq_last_error.restype = C.c_char_p
+    L.pvq_abi_version.argtypes = []; L.pvq_abi_version.restype = C.c_uint32
+    L.pvq_vqt_default_params.argtypes = [C.POINTER(CParams)]
+    L.pvq_vqt_create.argtypes = [C.POINTER(CParams), C.c_int, C.POINTER(vp), fp]; L.pvq_vqt_create.restype = C.c_int
+    L.pvq_vqt_destroy.argtypes = [vp]
+    L.pvq_vqt_get_params.argtypes = [vp, C.POINTER(CParams)]
+    L.pvq_vqt_n_bins.argtypes = [vp]; L.pvq_vqt_n_bins.restype = C.c_uint32
+    L.pvq_vqt_delay_seconds.argtypes = [vp]; L.pvq_vqt_delay_seconds.restype = C.c_double
+    L.pvq_vqt_window_union.argtypes = [vp]; L.pvq_vqt_window_union.restype = C.c_uint32
+    L.pvq_vqt_n_groups.argtypes = [vp]; L.pvq_vqt_n_groups.restype = C.c_uint32
+    L.pvq_vqt_group_info.argtypes = [vp, C.c_uint32, up]; L.pvq_vqt_group_info.restype = C.c_int
+    L.pvq_vqt_group_csr.argtypes = [vp, C.c_uint32, C.c_int, up, up, fp]; L.pvq_vqt_group_csr.restype = C.c_int
+    L.pvq_vqt_filter_params.argtypes = [vp, fp, fp, up, up]; L.pvq_vqt_filter_params.restype = C.c_int
+    L.pvq_vqt_calculate_instant_db.argtypes = [vp, fp, C.c_size_t, fp]; L.pvq_vqt_calculate_instant_db.restype = C.c_int
+    L.pvq_vqt_calculate_batch_db.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.c_size_t, fp]
+    L.pvq_vqt_calculate_batch_db.restype = C.c_int
+    L.pvq_vqt_calculate_batch_db_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp]
+    L.pvq_vqt_calculate_batch_db_device.restype = C.c_int
+    L.pvq_vqt_set_algo.argtypes = [vp, C.c_int]; L.pvq_vqt_set_algo.restype = C.c_int
+    L.pvq_vqt_last_algo.argtypes = [vp]; L.pvq_vqt_last_algo.restype = C.c_int
+    L.pvq_analysis_default_params.argtypes = [C.POINTER(CAnalysisParams)]
+    L.pvq_analyze_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(CAnalysisParams), vp, vp, vp, vp, C.c_uint32, vp]
+    L.pvq_analyze_batch_device.restype = C.c_int
+    L.pvq_analyze_batch.argtypes = [vp, fp, C.c_size_t, C.POINTER(CAnalysisParams), up, up, fp, fp, C.c_uint32]
+    L.pvq_analyze_batch.restype = C.c_int
+    L.pvq_vqt_analyze_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(CAnalysisParams),
+                                               vp, vp, vp, vp, vp, C.c_uint32, vp]
+    L.pvq_vqt_analyze_batch_device.restype = C.c_int
+    L.pvq_vqt_set_profiling.argtypes = [vp, C.c_int]; L.pvq_vqt_set_profiling.restype = C.c_int
+    L.pvq_vqt_last_kernel_ms.argtypes = [vp, fp, C.c_uint32]; L.pvq_vqt_last_kernel_ms.restype = C.c_uint32
+    L.pvq_vqt_kernel_name.argtypes = [C.c_uint32]; L.pvq_vqt_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L

@@ -1,0 +1,844 @@
+// vqt_engine.hip — MI355X (gfx950 / CDNA4) kernels and the pvq::Vqt engine.
+//
+// Hot path being replaced: Vqt::calculate_vqt_instant_in_db (reference
+// pitchvis_analysis/src/vqt.rs:866-916), power_to_db (:922-954) and the stateless peak pipeline
+// (analysis.rs:332-361, analysis_modules/peak_detection.rs:26-241), batched over hops.
+//
+// Kernel inventory (wave64, LDS-staged, no compatibility layers):
+//   vqt_fft_frames<BLOCK>   one workgroup per frame.  Per window group: gather the window from the
+//                           hop stream, an in-place register-staged Stockham FFT (radix 16/8/4/2)
+//                           of the packed real window in padded LDS, real-split of only the
+//                           columns the sparse kernel reads, banded complex row dots reduced with
+//                           16-lane shuffles; then the frame-relative dB epilogue.
+//   peaks_frames            one wavefront per frame: plateau-aware local maxima, prominence
+//                           walks, bass/general split, sub-bin refinement, bass promotion.
+//   (block-DFT path: see vqt_blockdft.hip)
+#include "vqt_engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "device_tables.hpp"
+
+namespace pvq {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+#define PVQ_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_last_error(std::string(#call) + " failed: " + hipGetErrorString(e_));              \
+            return PVQ_ERR_DEVICE;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// LDS padding: one float2 of padding after every 16, so that radix-16 strided writes
+// (stride 16 elements = 128 B) land on distinct banks within each 16-lane ds_write_b64 group.
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
+
+// cos/sin(2*pi*k/16), k = 0..7
+__device__ constexpr float kC16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                                      0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+__device__ constexpr float kS16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                                      1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+
+// In-register forward DFT of R points (natural order in and out), decimation in time.
+template <int R>
+struct RegFft;
+
+template <int R, int K>
+struct RegBfly {
+    static __device__ __forceinline__ void run(float2* u, const float2* e, const float2* o) {
+        constexpr int idx = K * (16 / R);  // twiddle exp(-2*pi*i*idx/16)
+        float2 t;
+        if constexpr (idx == 0) {
+            t = o[K];
+        } else if constexpr (idx == 4) {
+            t = make_float2(o[K].y, -o[K].x);  // * (-i)
+        } else {
+            t = cmul(o[K], make_float2(kC16[idx], -kS16[idx]));
+        }
+        u[K] = cadd(e[K], t);
+        u[K + R / 2] = csub(e[K], t);
+        if constexpr (K + 1 < R / 2) RegBfly<R, K + 1>::run(u, e, o);
+    }
+};
+
+template <>
+struct RegFft<1> {
+    static __device__ __forceinline__ void run(float2*) {}
+};
+template <>
+struct RegFft<2> {
+    static __device__ __forceinline__ void run(float2* u) {
+        float2 a = u[0], b = u[1];
+        u[0] = cadd(a, b);
+        u[1] = csub(a, b);
+    }
+};
+template <int R>
+struct RegFft {
+    static __device__ __forceinline__ void run(float2* u) {
+        float2 e[R / 2], o[R / 2];
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            e[k] = u[2 * k];
+            o[k] = u[2 * k + 1];
+        }
+        RegFft<R / 2>::run(e);
+        RegFft<R / 2>::run(o);
+        RegBfly<R, 0>::run(u, e, o);
+    }
+};
+
+// One in-place Stockham autosort pass of radix R over N points living in padded LDS.
+//   item i in [0, N/R): k = i mod p, u[r] = Z[i + r*N/R] * w_{pR}^{k r}, DFT_R, Z[(i-k)R + k + r p] = u[r]
+// Every thread first pulls all of its inputs into registers, the workgroup synchronises, then the
+// outputs go back into the same buffer: one LDS buffer serves any N <= E*BLOCK.
+template <int R, int BLOCK, int E>
+__device__ __forceinline__ void stockham_pass(float2* __restrict__ Z, int N, int p, const float2* __restrict__ tw,
+                                              int tw_stride, int tid) {
+    constexpr int NB = E / R;  // butterflies a thread may own
+    const int T = N / R;
+    float2 u[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * BLOCK;
+        if (i < T) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[b][r] = Z[lpad(i + r * T)];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * BLOCK;
+        if (i < T) {
+            if (p > 1) {
+                const int k = i & (p - 1);
+                const int base = k * tw_stride;
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[b][r] = cmul(u[b][r], tw[base * r]);
+            }
+            RegFft<R>::run(u[b]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * BLOCK;
+        if (i < T) {
+            const int k = i & (p - 1);
+            const int j = (i - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) Z[lpad(j + r * p)] = u[b][r];
+        }
+    }
+    __syncthreads();
+}
+
+// Full forward FFT of N = 2^logN complex points in padded LDS (natural order in and out).
+template <int BLOCK, int E>
+__device__ __forceinline__ void lds_fft(float2* Z, int N, const float2* tw, int n_tw, int tid) {
+    int p = 1;
+    int rem = N;
+    while (rem >= 16) {
+        stockham_pass<16, BLOCK, E>(Z, N, p, tw, n_tw / (p * 16), tid);
+        p *= 16;
+        rem >>= 4;
+    }
+    if (rem == 8) {
+        stockham_pass<8, BLOCK, E>(Z, N, p, tw, n_tw / (p * 8), tid);
+    } else if (rem == 4) {
+        stockham_pass<4, BLOCK, E>(Z, N, p, tw, n_tw / (p * 4), tid);
+    } else if (rem == 2) {
+        stockham_pass<2, BLOCK, E>(Z, N, p, tw, n_tw / (p * 2), tid);
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// vqt.rs:922-954 constants
+#define PVQ_REF_POWER (0.3f * 0.3f)
+#define PVQ_A_MIN (1e-6f * 1e-6f)
+#define PVQ_TOP_DB 60.0f
+
+// Frame-relative dB epilogue shared by both algorithm paths.  xv: n_bins complex coefficients in
+// LDS; red: 2*(BLOCK/64) floats of LDS scratch.  Writes n_bins floats to out (global).
+template <int BLOCK>
+__device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_bins, float* __restrict__ out,
+                                            int tid) {
+    const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
+    constexpr int NW = BLOCK / 64;
+    constexpr int PER = 4;  // supports n_bins <= 4*BLOCK
+    float d[PER];
+    float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = tid + t * BLOCK;
+        d[t] = 0.0f;
+        if (k < n_bins) {
+            const float2 z = xv[k];
+            const float ns = z.x * z.x + z.y * z.y;
+            d[t] = 10.0f * log10f(fmaxf(ns, PVQ_A_MIN)) - ref_db;
+            mx = fmaxf(mx, d[t]);
+            mn = fminf(mn, d[t]);
+        }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = mx;
+        red[NW + (tid >> 6)] = mn;
+    }
+    __syncthreads();
+    mx = red[0];
+    mn = red[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        mx = fmaxf(mx, red[w]);
+        mn = fminf(mn, red[NW + w]);
+    }
+    const float floor_db = mx - PVQ_TOP_DB;
+    mn = fmaxf(mn, floor_db);
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = tid + t * BLOCK;
+        if (k < n_bins) {
+            const float c = fmaxf(d[t], floor_db);
+            out[k] = (mn > 0.0f) ? (c - mn) : fmaxf(c, 0.0f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1-K3 fused: FFT path, one workgroup per frame
+// ------------------------------------------------------------------------------------------------
+struct FftArgs {
+    const float* pcm;
+    long long n_lead;
+    long long hop;
+    long long n_samples;  // total samples in pcm (for upper-bound safety)
+    int n_fft;
+    int n_frames;
+    int n_groups;
+    int n_bins;
+    int n_tw;       // twiddle table length (= largest complex FFT size)
+    int max_cols;   // LDS spec capacity
+    const GroupDev* groups;
+    const float2* tw;
+    const float2* split_tw;
+    const uint32_t* row_ptr;
+    const float2* ent_val;
+    const uint16_t* ent_col;
+    float* out_db;
+    float2* out_cplx;
+};
+
+template <int BLOCK, int E>
+__global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* Z = reinterpret_cast<float2*>(smem);
+    float2* spec = Z + lpad(a.n_tw) + 1;
+    float2* xv = spec + a.max_cols;
+    float* red = reinterpret_cast<float*>(xv + a.n_bins);
+    const int tid = threadIdx.x;
+
+    for (int frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
+        // x[j] of the reference's n_fft buffer is pcm[buf0 + j]; zeros before the stream start
+        const long long buf0 = a.n_lead + (long long)(frame + 1) * a.hop - a.n_fft;
+
+        for (int g = 0; g < a.n_groups; ++g) {
+            const GroupDev G = a.groups[g];
+            const int N = G.n_cplx;
+            // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]), as a flat float copy
+            {
+                float* Zf = reinterpret_cast<float*>(Z);
+                const long long s0 = buf0 + G.w0;
+                for (int i = tid; i < 2 * N; i += BLOCK) {
+                    const long long s = s0 + i;
+                    const float v = (s >= 0 && s < a.n_samples) ? a.pcm[s] : 0.0f;
+                    Zf[2 * lpad(i >> 1) + (i & 1)] = v;
+                }
+            }
+            __syncthreads();
+            lds_fft<BLOCK, E>(Z, N, a.tw, a.n_tw, tid);
+            // real split, only for the columns the kernel reads (c <= n_cols-1 <= N)
+            for (int c = tid; c < G.n_cols; c += BLOCK) {
+                const float2 za = Z[lpad(c & (N - 1))];
+                float2 zb = Z[lpad((N - c) & (N - 1))];
+                zb.y = -zb.y;
+                const float2 w = a.split_tw[G.split_off + c];
+                const float2 ev = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
+                const float2 dv = make_float2(0.5f * (za.x - zb.x), 0.5f * (za.y - zb.y));
+                const float2 t = cmul(w, dv);
+                spec[c] = make_float2(ev.x + t.y, ev.y - t.x);
+            }
+            __syncthreads();
+            // banded complex row dots: 16 lanes per row
+            {
+                const int sub = tid >> 4, l16 = tid & 15;
+                const uint32_t* rp = a.row_ptr + G.row_ptr_off;
+                for (int row = sub; row < G.n_rows; row += BLOCK / 16) {
+                    const int s = G.ent_off + rp[row], e = G.ent_off + rp[row + 1];
+                    float2 acc = make_float2(0.0f, 0.0f);
+                    for (int i = s + l16; i < e; i += 16) {
+                        const float2 v = a.ent_val[i];
+                        const uint32_t c = a.ent_col[i];
+                        float2 x = spec[c & 0x7fffu];
+                        if (c & 0x8000u) x.y = -x.y;
+                        acc.x += v.x * x.x - v.y * x.y;
+                        acc.y += v.x * x.y + v.y * x.x;
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {
+                        acc.x += __shfl_xor(acc.x, o);
+                        acc.y += __shfl_xor(acc.y, o);
+                    }
+                    if (l16 == 0) xv[G.first_bin + row] = acc;
+                }
+            }
+            // no barrier needed here: the next group's gather only writes Z (spec/xv untouched)
+            // and its FFT passes synchronise before spec is rewritten.
+        }
+        __syncthreads();
+        if (a.out_cplx) {
+            for (int k = tid; k < a.n_bins; k += BLOCK) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
+        }
+        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, tid);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: peaks, one wavefront per frame
+// ------------------------------------------------------------------------------------------------
+struct PeakArgs {
+    const float* db;
+    int n_frames;
+    int n_bins;
+    int bpo;
+    int octaves;
+    float min_freq;
+    const float* lnf;  // ln(f_k), host-computed
+    AnalysisParameters ap;
+    int dist;     // round(bpo*0.4/12), peak_detection.rs:37
+    int min_bin;  // ceil((bpo/12)/2), peak_detection.rs:45
+    uint32_t* mask;
+    uint32_t* count;
+    float* center;
+    float* size;
+    uint32_t max_peaks;
+};
+
+constexpr int PK_MAXB = 1024;  // max bins per frame
+constexpr int PK_WAVES = 4;
+
+__device__ __forceinline__ float clampf_dev(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// scipy-style greedy distance suppression among the candidates that pass `min_height`
+// (find_peaks 0.1.5 with_min_distance; only reached when dist > 1, e.g. 84 bins/octave).
+// Runs on lane 0: the candidate list is short.  keep[] bit per bin, in LDS.
+__device__ void distance_filter_serial(const float* x, int n, const uint8_t* cand, float min_height, int dist,
+                                       uint8_t* keep, uint16_t* list) {
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        keep[i] = 0;
+        if (cand[i] && x[i] >= min_height) list[np++] = (uint16_t)i;
+    }
+    // stable insertion sort ascending by height (ties keep ascending bin order)
+    // order stored in the upper half of list
+    uint16_t* order = list + PK_MAXB / 2;
+    for (int a = 0; a < np; ++a) order[a] = (uint16_t)a;
+    for (int a = 1; a < np; ++a) {
+        const uint16_t t = order[a];
+        int b = a;
+        while (b > 0 && x[list[order[b - 1]]] > x[list[t]]) {
+            order[b] = order[b - 1];
+            --b;
+        }
+        order[b] = t;
+    }
+    for (int a = 0; a < np; ++a) keep[list[a]] = 1;
+    for (int a = np - 1; a >= 0; --a) {
+        const int j = order[a];
+        if (!keep[list[j]]) continue;
+        for (int b = j - 1; b >= 0 && (int)list[j] - (int)list[b] < dist; --b) keep[list[b]] = 0;
+        for (int b = j + 1; b < np && (int)list[b] - (int)list[j] < dist; ++b) keep[list[b]] = 0;
+    }
+}
+
+
+// enhance_peaks_continuous (peak_detection.rs:61-148) followed by
+// promote_bass_peaks_with_harmonics (peak_detection.rs:172-241) for one peak.
+// The parabola fit in ln-frequency is ill-conditioned in f32 (differences of ~0.02 between
+// abscissae of ~6), so it is evaluated exactly as the CPU reference does: abscissae from the
+// host-computed table, no FMA contraction.
+__device__ __noinline__ void refine_peak(const float* x, int p, int nb, const PeakArgs& a, float& ctr, float& sz) {
+#pragma clang fp contract(off)
+    const float bpo = (float)a.bpo;
+    if (p < 1 || p > nb - 2) {
+        ctr = (float)p;
+        sz = x[p];
+    } else {
+        const float l0 = a.lnf[p - 1], l1 = a.lnf[p], l2 = a.lnf[p + 1];
+        const float a0 = x[p - 1], a1 = x[p], a2 = x[p + 1];
+        const float denom = (l0 - l1) * (l0 - l2) * (l1 - l2);
+        if (fabsf(denom) < 1.1920929e-07f) {
+            ctr = (float)p;
+            sz = x[p];
+        } else {
+            const float qa = (l2 * (a1 - a0) + l0 * (a2 - a1) + l1 * (a0 - a2)) / denom;
+            const float qb = ((l2 * l2) * (a0 - a1) + (l0 * l0) * (a1 - a2) + (l1 * l1) * (a2 - a0)) / denom;
+            const float lfp = (fabsf(qa) < 1.1920929e-07f) ? l1 : clampf_dev(-qb / (2.0f * qa), l0, l2);
+            const float f_peak = expf(lfp);
+            const float est = bpo * log2f(f_peak / a.min_freq);
+            const float cc = clampf_dev(est, 0.0f, (float)nb - 1.0f);
+            const int lower = (int)floorf(cc);
+            const int upper = min(lower + 1, nb - 1);
+            const float fract = cc - truncf(cc);
+            ctr = cc;
+            sz = fmaxf(x[lower] * (1.0f - fract) + x[upper] * fract, 0.0f);
+        }
+    }
+    if (!(ctr > (float)a.ap.highest_bassnote)) {
+        const float f0 = a.min_freq * powf(2.0f, ctr / bpo);
+        const float p0 = powf(10.0f, sz / 10.0f);
+        float score = 0.0f;
+        const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
+#pragma unroll
+        for (int h = 2; h <= 5; ++h) {
+            const float hf = f0 * (float)h;
+            if (hf >= a.min_freq) {
+                const float hb = (log2f(hf) - log2f(a.min_freq)) * bpo;
+                if (hb >= 0.0f && hb < (float)nb) {
+                    const int lo = (int)floorf(hb);
+                    const int hi = min((int)ceilf(hb), nb - 1);
+                    const float frac = hb - truncf(hb);
+                    const float adb = (lo == hi) ? x[lo] : (x[lo] * (1.0f - frac) + x[hi] * frac);
+                    const float hp = powf(10.0f, adb / 10.0f);
+                    if (hp > p0 * a.ap.harmonic_threshold) score += hp * wts[h - 2];
+                }
+            }
+        }
+        if (score > 0.0f) {
+            const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
+            sz += 10.0f * log10f(boost);
+        }
+    }
+}
+
+__global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames(PeakArgs a) {
+    __shared__ float s_x[PK_WAVES][PK_MAXB];
+    __shared__ float s_prom[PK_WAVES][PK_MAXB];
+    __shared__ uint8_t s_cand[PK_WAVES][PK_MAXB];
+    __shared__ uint8_t s_keep[PK_WAVES][2][PK_MAXB];
+    __shared__ uint16_t s_list[PK_WAVES][PK_MAXB];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = a.n_bins;
+    const int words = (n + 31) / 32;
+
+    for (int frame = blockIdx.x * PK_WAVES + wv; frame < a.n_frames; frame += gridDim.x * PK_WAVES) {
+        float* x = s_x[wv];
+        float* prom = s_prom[wv];
+        uint8_t* cand = s_cand[wv];
+        const float* src = a.db + (size_t)frame * n;
+        for (int i = lane; i < n; i += 64) {
+            x[i] = src[i];
+            cand[i] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // plateau-aware local maxima + prominence (find_peaks 0.1.5 semantics: scipy-like)
+        for (int i = lane; i < n; i += 64) {
+            if (i >= 1 && i < n - 1 && x[i - 1] < x[i]) {
+                int ia = i + 1;
+                while (ia < n - 1 && x[ia] == x[i]) ++ia;
+                if (x[ia] < x[i]) {
+                    const int mid = (i + ia) >> 1;
+                    const float h = x[mid];
+                    float lmin = h, rmin = h;
+                    for (int q = mid - 1; q >= 0; --q) {
+                        const float v = x[q];
+                        if (v > h) break;
+                        lmin = fminf(lmin, v);
+                    }
+                    for (int q = mid + 1; q < n; ++q) {
+                        const float v = x[q];
+                        if (v > h) break;
+                        rmin = fminf(rmin, v);
+                    }
+                    prom[mid] = h - fmaxf(lmin, rmin);
+                    cand[mid] = 1;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (a.dist > 1) {
+            if (lane == 0) {
+                distance_filter_serial(x, n, cand, a.ap.bass_min_height, a.dist, s_keep[wv][0], s_list[wv]);
+                distance_filter_serial(x, n, cand, a.ap.peak_min_height, a.dist, s_keep[wv][1], s_list[wv]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+        // final selection, ordered compaction and continuous refinement
+        uint32_t total = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool is_peak = false;
+            if (i < n && cand[i] && i >= a.min_bin) {
+                const float h = x[i], pr = prom[i];
+                if (i <= (int)a.ap.highest_bassnote) {
+                    is_peak = h >= a.ap.bass_min_height && pr >= a.ap.bass_min_prominence &&
+                              (a.dist <= 1 || s_keep[wv][0][i]);
+                } else {
+                    is_peak = h >= a.ap.peak_min_height && pr >= a.ap.peak_min_prominence &&
+                              (a.dist <= 1 || s_keep[wv][1][i]);
+                }
+            }
+            const unsigned long long bal = __ballot(is_peak);
+            if (a.mask) {
+                if (lane == 0 && (base >> 5) < words) a.mask[(size_t)frame * words + (base >> 5)] = (uint32_t)bal;
+                if (lane == 1 && (base >> 5) + 1 < words)
+                    a.mask[(size_t)frame * words + (base >> 5) + 1] = (uint32_t)(bal >> 32);
+            }
+            const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+            const uint32_t slot = total + before;
+            total += __popcll(bal);
+            if (is_peak && a.center && slot < a.max_peaks) {
+                float ctr, sz;
+                refine_peak(x, i, n, a, ctr, sz);
+                a.center[(size_t)frame * a.max_peaks + slot] = ctr;
+                a.size[(size_t)frame * a.max_peaks + slot] = sz;
+            }
+        }
+        if (a.count && lane == 0) a.count[frame] = total;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+const char* Vqt::slot_name(uint32_t s) {
+    switch (s) {
+        case SLOT_FFT_FRAMES: return "vqt_fft_frames";
+        case SLOT_BLOCKDFT_GEMM: return "blockdft_gemm";
+        case SLOT_BLOCKDFT_COMBINE: return "blockdft_combine";
+        case SLOT_PEAKS: return "peaks_frames";
+        default: return "";
+    }
+}
+
+pvq_status Vqt::create(const VqtParameters& p, int device_id, std::unique_ptr<Vqt>& out, VqtError& err) {
+    if (p.range.octaves == 0 || p.range.buckets_per_octave == 0 || p.n_fft < 4 || (p.n_fft & (p.n_fft - 1)) != 0 ||
+        !(p.sr > 0.0f) || !(p.range.min_freq > 0.0f)) {
+        set_last_error("invalid VqtParameters (n_fft must be a power of two, sr/min_freq/octaves/buckets > 0)");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    std::unique_ptr<Vqt> v(new Vqt());
+    err = build_plan(p, v->plan_);
+    if (err.kind == VqtError::AboveNyquist) {
+        set_last_error(err.to_string());
+        return PVQ_ERR_ABOVE_NYQUIST;
+    }
+    if (err.kind == VqtError::WindowExceedsNFft) {
+        set_last_error(err.to_string());
+        return PVQ_ERR_WINDOW_EXCEEDS_NFFT;
+    }
+    v->device_id_ = device_id;
+    if (device_id >= 0) {
+        int n_dev = 0;
+        hipError_t e = hipGetDeviceCount(&n_dev);
+        if (e != hipSuccess || device_id >= n_dev) {
+            set_last_error("no such HIP device (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ")");
+            return PVQ_ERR_DEVICE;
+        }
+        PVQ_HIP(hipSetDevice(device_id));
+        pvq_status st = v->upload_tables();
+        if (st != PVQ_OK) return st;
+    }
+    out = std::move(v);
+    return PVQ_OK;
+}
+
+Vqt::~Vqt() {
+    if (device_id_ >= 0) {
+        (void)hipSetDevice(device_id_);
+        if (dev_) {
+            free_device_tables(dev_);
+            dev_ = nullptr;
+        }
+        if (ws_pcm_) (void)hipFree(ws_pcm_);
+        if (ws_out_) (void)hipFree(ws_out_);
+        if (ws_misc_) (void)hipFree(ws_misc_);
+        if (ev_created_)
+            for (int s = 0; s < N_SLOTS; ++s) {
+                (void)hipEventDestroy(ev_[s][0]);
+                (void)hipEventDestroy(ev_[s][1]);
+            }
+    }
+}
+
+pvq_status Vqt::upload_tables() {
+    std::string msg;
+    dev_ = build_device_tables(plan_, msg);
+    if (!dev_) {
+        set_last_error(msg);
+        return msg.rfind("unsupported", 0) == 0 ? PVQ_ERR_UNSUPPORTED : PVQ_ERR_DEVICE;
+    }
+    return PVQ_OK;
+}
+
+pvq_status Vqt::ensure_workspace(void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return PVQ_OK;
+    if (*ptr) PVQ_HIP(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    PVQ_HIP(hipMalloc(ptr, bytes));
+    *cap = bytes;
+    return PVQ_OK;
+}
+
+void Vqt::slot_begin(int slot, hipStream_t s) {
+    if (!profiling_) return;
+    if (!ev_created_) {
+        for (int i = 0; i < N_SLOTS; ++i) {
+            (void)hipEventCreate(&ev_[i][0]);
+            (void)hipEventCreate(&ev_[i][1]);
+        }
+        ev_created_ = true;
+    }
+    (void)hipEventRecord(ev_[slot][0], s);
+    ev_used_[slot] = true;
+}
+void Vqt::slot_end(int slot, hipStream_t s) {
+    if (!profiling_) return;
+    (void)hipEventRecord(ev_[slot][1], s);
+}
+
+uint32_t Vqt::last_kernel_ms(float* out, uint32_t cap) {
+    uint32_t n = 0;
+    for (int s = 0; s < N_SLOTS && (uint32_t)s < cap; ++s) {
+        out[s] = -1.0f;
+        if (ev_created_ && ev_used_[s]) {
+            if (hipEventSynchronize(ev_[s][1]) == hipSuccess) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, ev_[s][0], ev_[s][1]) == hipSuccess) out[s] = ms;
+            }
+        }
+        n = s + 1;
+    }
+    return n;
+}
+
+pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
+                                float* d_out_cplx, hipStream_t stream) {
+    FftArgs a;
+    a.pcm = d_pcm;
+    a.n_lead = (long long)n_lead;
+    a.hop = (long long)hop;
+    a.n_samples = (long long)(n_lead + n_frames * hop);
+    a.n_fft = (int)plan_.params.n_fft;
+    a.n_frames = (int)n_frames;
+    a.n_groups = (int)plan_.kernel.window_groups.size();
+    a.n_bins = (int)n_bins();
+    a.n_tw = dev_->n_tw;
+    a.max_cols = dev_->max_cols;
+    a.groups = dev_->d_groups;
+    a.tw = dev_->d_tw;
+    a.split_tw = dev_->d_split_tw;
+    a.row_ptr = dev_->d_row_ptr;
+    a.ent_val = dev_->d_ent_val;
+    a.ent_col = dev_->d_ent_col;
+    a.out_db = d_out_db;
+    a.out_cplx = reinterpret_cast<float2*>(d_out_cplx);
+
+    const size_t lds = sizeof(float2) * ((size_t)(dev_->n_tw + (dev_->n_tw >> 4)) + 1 + dev_->max_cols + a.n_bins) +
+                       sizeof(float) * 2 * 16;
+    const int grid = (int)std::min<size_t>(n_frames, 1u << 20);
+    slot_begin(SLOT_FFT_FRAMES, stream);
+    if (dev_->n_tw <= 512 * 16) {
+        auto kern = vqt_fft_frames<512, 16>;
+        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        auto kern = vqt_fft_frames<1024, 16>;
+        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, a);
+    }
+    slot_end(SLOT_FFT_FRAMES, stream);
+    PVQ_HIP(hipGetLastError());
+    last_algo_ = PVQ_ALGO_FFT;
+    return PVQ_OK;
+}
+
+pvq_status Vqt::calculate_batch_db_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
+                                          float* d_out_db, float* d_out_cplx, hipStream_t stream) {
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if (n_frames == 0) return PVQ_OK;
+    if (!d_pcm || !d_out_db || hop == 0 || n_frames > (size_t)0x7fffffff) {
+        set_last_error("calculate_batch: null pointer, zero hop or too many frames");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    PVQ_HIP(hipSetDevice(device_id_));
+    for (int s = 0; s < N_SLOTS; ++s) ev_used_[s] = false;
+    bool use_block = false;
+    if (algo_ == PVQ_ALGO_BLOCKDFT) {
+        if (!blockdft_applicable(hop)) {
+            set_last_error("block-DFT path needs a power-of-two hop that divides every analysis window");
+            return PVQ_ERR_UNSUPPORTED;
+        }
+        use_block = true;
+    } else if (algo_ == PVQ_ALGO_AUTO) {
+        use_block = blockdft_applicable(hop) && n_frames >= 64;
+    }
+    if (use_block) return launch_blockdft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, stream);
+    return launch_fft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, stream);
+}
+
+pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, size_t n_frames, float* out_db) {
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if (n_frames == 0) return PVQ_OK;
+    if (!pcm || !out_db || hop == 0) {
+        set_last_error("calculate_batch: null pointer or zero hop");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    PVQ_HIP(hipSetDevice(device_id_));
+    const size_t n_samples = n_lead + n_frames * hop;
+    pvq_status st = ensure_workspace(&ws_pcm_, &ws_pcm_cap_, n_samples * sizeof(float));
+    if (st != PVQ_OK) return st;
+    st = ensure_workspace(&ws_out_, &ws_out_cap_, n_frames * n_bins() * sizeof(float));
+    if (st != PVQ_OK) return st;
+    PVQ_HIP(hipMemcpy(ws_pcm_, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice));
+    st = calculate_batch_db_device(static_cast<const float*>(ws_pcm_), n_lead, hop, n_frames,
+                                   static_cast<float*>(ws_out_), nullptr, nullptr);
+    if (st != PVQ_OK) return st;
+    PVQ_HIP(hipMemcpy(out_db, ws_out_, n_frames * n_bins() * sizeof(float), hipMemcpyDeviceToHost));
+    return PVQ_OK;
+}
+
+pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* out_db) {
+    if (len != plan_.params.n_fft) {
+        set_last_error("input must be exactly n_fft samples");
+        return PVQ_ERR_BAD_LENGTH;
+    }
+    // one frame whose n_fft buffer is exactly x: hop = n_fft, no lead
+    return calculate_batch_db(x, 0, plan_.params.n_fft, 1, out_db);
+}
+
+pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const AnalysisParameters& ap,
+                                     uint32_t* d_peak_mask, uint32_t* d_peak_count, float* d_center, float* d_size,
+                                     uint32_t max_peaks, hipStream_t stream) {
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if (n_frames == 0) return PVQ_OK;
+    if (!d_db || ((d_center == nullptr) != (d_size == nullptr))) {
+        set_last_error("analyze_batch: null dB pointer, or only one of center/size given");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    if (n_bins() > (uint32_t)PK_MAXB || n_bins() < 3) {
+        set_last_error("unsupported: peak kernel handles 3..1024 bins per frame");
+        return PVQ_ERR_UNSUPPORTED;
+    }
+    PVQ_HIP(hipSetDevice(device_id_));
+    PeakArgs a;
+    a.db = d_db;
+    a.n_frames = (int)n_frames;
+    a.n_bins = (int)n_bins();
+    a.bpo = (int)plan_.params.range.buckets_per_octave;
+    a.octaves = (int)plan_.params.range.octaves;
+    a.min_freq = plan_.params.range.min_freq;
+    a.lnf = dev_->d_lnf;
+    a.ap = ap;
+    a.dist = (int)std::lround((float)a.bpo * 0.4f / 12.0f);
+    a.min_bin = ((a.bpo / 12) + 1) / 2;
+    a.mask = d_peak_mask;
+    a.count = d_peak_count;
+    a.center = d_center;
+    a.size = d_size;
+    a.max_peaks = max_peaks;
+    const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
+    slot_begin(SLOT_PEAKS, stream);
+    hipLaunchKernelGGL(peaks_frames, dim3(grid), dim3(PK_WAVES * 64), 0, stream, a);
+    slot_end(SLOT_PEAKS, stream);
+    PVQ_HIP(hipGetLastError());
+    return PVQ_OK;
+}
+
+pvq_status Vqt::analyze_batch(const float* db, size_t n_frames, const AnalysisParameters& ap, uint32_t* peak_mask,
+                              uint32_t* peak_count, float* center, float* size, uint32_t max_peaks) {
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if (n_frames == 0) return PVQ_OK;
+    if (!db) {
+        set_last_error("analyze_batch: null dB pointer");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    PVQ_HIP(hipSetDevice(device_id_));
+    const size_t nb = n_bins(), words = (nb + 31) / 32;
+    const size_t b_db = n_frames * nb * sizeof(float);
+    const size_t b_mask = n_frames * words * sizeof(uint32_t);
+    const size_t b_cnt = n_frames * sizeof(uint32_t);
+    const size_t b_pk = n_frames * (size_t)max_peaks * sizeof(float);
+    pvq_status st = ensure_workspace(&ws_out_, &ws_out_cap_, b_db);
+    if (st != PVQ_OK) return st;
+    st = ensure_workspace(&ws_misc_, &ws_misc_cap_, b_mask + b_cnt + 2 * b_pk + 64);
+    if (st != PVQ_OK) return st;
+    char* base = static_cast<char*>(ws_misc_);
+    uint32_t* d_mask = reinterpret_cast<uint32_t*>(base);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base + b_mask);
+    float* d_ctr = reinterpret_cast<float*>(base + b_mask + b_cnt);
+    float* d_sz = reinterpret_cast<float*>(base + b_mask + b_cnt + b_pk);
+    PVQ_HIP(hipMemcpy(ws_out_, db, b_db, hipMemcpyHostToDevice));
+    if (max_peaks) PVQ_HIP(hipMemset(d_ctr, 0, 2 * b_pk));
+    st = analyze_batch_device(static_cast<const float*>(ws_out_), n_frames, ap, d_mask, d_cnt,
+                              max_peaks ? d_ctr : nullptr, max_peaks ? d_sz : nullptr, max_peaks, nullptr);
+    if (st != PVQ_OK) return st;
+    PVQ_HIP(hipDeviceSynchronize());
+    if (peak_mask) PVQ_HIP(hipMemcpy(peak_mask, d_mask, b_mask, hipMemcpyDeviceToHost));
+    if (peak_count) PVQ_HIP(hipMemcpy(peak_count, d_cnt, b_cnt, hipMemcpyDeviceToHost));
+    if (center && max_peaks) PVQ_HIP(hipMemcpy(center, d_ctr, b_pk, hipMemcpyDeviceToHost));
+    if (size && max_peaks) PVQ_HIP(hipMemcpy(size, d_sz, b_pk, hipMemcpyDeviceToHost));
+    return PVQ_OK;
+}
+
+}  // namespace pvq

@@ -1,0 +1,95 @@
+// vqt_engine.hpp — pvq::Vqt, the GPU-backed mirror of pitchvis_analysis::vqt::Vqt
+// (reference pitchvis_analysis/src/vqt.rs:440-513, :866-916) plus the stateless per-frame peak
+// pipeline of AnalysisState::preprocess (analysis.rs:332-361).  One instance owns its host plan,
+// its device-resident kernel/twiddle tables and a grow-only device workspace; like the
+// reference's `&mut self` it is exclusive to one caller at a time.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pvq.h"
+#include "vqt_host.hpp"
+
+namespace pvq {
+
+// analysis.rs:72-98 (peak-related fields)
+struct AnalysisParameters {
+    float peak_min_prominence = 10.0f;
+    float peak_min_height = 4.0f;
+    float bass_min_prominence = 5.0f;
+    float bass_min_height = 3.5f;
+    uint32_t highest_bassnote = 28;
+    float harmonic_threshold = 0.3f;
+};
+
+struct DeviceTables;  // opaque (vqt_engine.hip)
+
+class Vqt {
+   public:
+    // Vqt::new, vqt.rs:465.  device_id < 0: host-only plan.
+    static pvq_status create(const VqtParameters& p, int device_id, std::unique_ptr<Vqt>& out, VqtError& err);
+    ~Vqt();
+
+    const VqtParameters& params() const { return plan_.params; }  // vqt.rs:507
+    const VqtKernel& kernel() const { return plan_.kernel; }      // vqt.rs:511
+    const HostPlan& plan() const { return plan_; }
+    double delay_seconds() const { return plan_.delay_seconds; }  // vqt.rs:449
+    uint32_t n_bins() const { return plan_.params.range.n_buckets(); }
+    bool has_device() const { return device_id_ >= 0; }
+
+    // vqt.rs:866 (host pointers, synchronous)
+    pvq_status calculate_vqt_instant_in_db(const float* x, size_t len, float* out_db);
+    pvq_status calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, size_t n_frames, float* out_db);
+    // device pointers, asynchronous on `stream`
+    pvq_status calculate_batch_db_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
+                                         float* d_out_db, float* d_out_cplx, hipStream_t stream);
+    pvq_status analyze_batch_device(const float* d_db, size_t n_frames, const AnalysisParameters& a,
+                                    uint32_t* d_peak_mask, uint32_t* d_peak_count, float* d_center,
+                                    float* d_size, uint32_t max_peaks, hipStream_t stream);
+    pvq_status analyze_batch(const float* db, size_t n_frames, const AnalysisParameters& a, uint32_t* peak_mask,
+                             uint32_t* peak_count, float* center, float* size, uint32_t max_peaks);
+
+    void set_algo(pvq_algo a) { algo_ = a; }
+    pvq_algo last_algo() const { return last_algo_; }
+    void set_profiling(bool on) { profiling_ = on; }
+    uint32_t last_kernel_ms(float* out, uint32_t cap);
+
+    enum KernelSlot { SLOT_FFT_FRAMES = 0, SLOT_BLOCKDFT_GEMM = 1, SLOT_BLOCKDFT_COMBINE = 2, SLOT_PEAKS = 3, N_SLOTS = 4 };
+    static const char* slot_name(uint32_t s);
+
+   private:
+    Vqt() = default;
+    pvq_status upload_tables();
+    pvq_status launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
+                               float* d_out_cplx, hipStream_t stream);
+    bool blockdft_applicable(size_t hop) const;
+    pvq_status prepare_blockdft(size_t hop);
+    pvq_status launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
+                                    float* d_out_db, float* d_out_cplx, hipStream_t stream);
+    pvq_status ensure_workspace(void** ptr, size_t* cap, size_t bytes);
+    void slot_begin(int slot, hipStream_t s);
+    void slot_end(int slot, hipStream_t s);
+
+    HostPlan plan_;
+    int device_id_ = -1;
+    DeviceTables* dev_ = nullptr;
+    pvq_algo algo_ = PVQ_ALGO_AUTO;
+    pvq_algo last_algo_ = PVQ_ALGO_AUTO;
+    bool profiling_ = false;
+    hipEvent_t ev_[N_SLOTS][2] = {};
+    bool ev_used_[N_SLOTS] = {};
+    bool ev_created_ = false;
+    // grow-only workspaces for the host-pointer wrappers
+    void* ws_pcm_ = nullptr;  size_t ws_pcm_cap_ = 0;
+    void* ws_out_ = nullptr;  size_t ws_out_cap_ = 0;
+    void* ws_misc_ = nullptr; size_t ws_misc_cap_ = 0;
+};
+
+void set_last_error(const std::string& s);
+const char* get_last_error();
+
+}  // namespace pvq

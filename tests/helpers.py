@@ -1,0 +1,65 @@
+"""Shared geometry definitions and synthetic-input generators for the test-suite."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle as O
+
+
+def geom_pair(sr, min_freq, octaves, bpo, **kw):
+    """(pitchvis_amd.VqtParameters, oracle.OracleParams) for the same geometry."""
+    import pitchvis_amd as P
+    return (P.VqtParameters(sr=sr, range=P.VqtRange(min_freq, octaves, bpo), **kw),
+            O.OracleParams(sr=sr, min_freq=min_freq, octaves=octaves, buckets_per_octave=bpo, **kw))
+
+
+# BASELINE.json geometries + the reference's two shipped configurations
+GEOMS = {
+    "default_22k_588": dict(sr=22050.0, min_freq=55.0, octaves=7, bpo=84),          # vqt.rs:180-214
+    "bench_48k_252": dict(sr=48000.0, min_freq=55.0, octaves=7, bpo=36),            # configs 1,2,5
+    "bench_48k_288": dict(sr=48000.0, min_freq=55.0, octaves=8, bpo=36),            # config 3
+    "hires_96k_360": dict(sr=96000.0, min_freq=27.5, octaves=10, bpo=36),           # config 4 (lean)
+    "hires_96k_840": dict(sr=96000.0, min_freq=27.5, octaves=10, bpo=84),           # config 4 (high-res)
+    "serial_22k_180": dict(sr=22050.0, min_freq=55.0, octaves=5, bpo=36, quality=1.8, gamma=4.8 * 1.8),  # pitchvis_serial/src/main.rs:17-39
+}
+
+
+def get_geom(name):
+    g = dict(GEOMS[name])
+    return geom_pair(g.pop("sr"), g.pop("min_freq"), g.pop("octaves"), g.pop("bpo"), **g)
+
+
+def white_noise(n, seed, amp=0.25):
+    """uniform in [-amp, amp), fp32 (BASELINE config 2 style)"""
+    rng = np.random.default_rng(seed)
+    return ((rng.random(n, dtype=np.float32) - 0.5) * (2.0 * amp)).astype(np.float32)
+
+
+def sine_sweep(n, sr, f0=55.0, f1=6900.0, amp=1.0 / 12.0):
+    """exponential sweep, phase accumulated in f64 (BASELINE config 1 style)"""
+    t = np.arange(n, dtype=np.float64) / sr
+    T = n / sr
+    k = np.log(f1 / f0) / T
+    phase = 2.0 * np.pi * f0 * (np.exp(k * t) - 1.0) / k
+    return (amp * np.sin(phase)).astype(np.float32)
+
+
+def three_regime(n, sr, seed):
+    """silent | moderate noise + tones (clip branch of power_to_db) | loud dense chord over noise
+    (shift branch: every bin > 0 dB) — SURVEY.md Appendix A.6."""
+    a = n // 3
+    rng = np.random.default_rng(seed)
+    x = np.zeros(n, np.float32)
+    t = np.arange(n, dtype=np.float64) / sr
+    mod = 0.02 * (rng.random(n) - 0.5) + 0.1 * np.sin(2 * np.pi * 440.0 * t) + 0.05 * np.sin(2 * np.pi * 1318.5 * t)
+    loud = 8.0 * (rng.random(n) - 0.5)
+    for k in range(0, 80):
+        loud += 0.5 * np.sin(2 * np.pi * 55.0 * 2 ** (k / 12.0) * t + k)
+    x[a:2 * a] = mod[a:2 * a]
+    x[2 * a:] = loud[2 * a:]
+    return x
+
+
+def mask_to_indices(mask_row, n_bins):
+    bits = np.unpackbits(np.ascontiguousarray(mask_row).view(np.uint8), bitorder="little")[:n_bins]
+    return np.nonzero(bits)[0]

@@ -1,0 +1,254 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances (fp32 path; north_star: magnitudes within 1e-5 relative of the CPU path):
+  * complex coefficients: |z_gpu - z_cpu| <= 1e-5 * S for every bin, where S is the largest
+    magnitude in that frame — or, for frames whose output is tiny compared with their input (e.g.
+    the first frames after silence, where the signal sits only in the Hann tails and the
+    coefficients are the residue of large cancelling terms), 1 % of the response a sine of the
+    window's peak amplitude would give (0.01 * sqrt(sr) * max|x|): the error of ANY fp32
+    evaluation scales with the input, not with the cancelled output;
+  * magnitudes, per bin, relative: <= 1e-5 for every bin within 20 dB (1e-1) of the frame maximum
+    (weaker bins carry the absolute error of two different fp32 FFT orderings; they are covered by
+    the first bound and by the f64 check below);
+  * against the exact-in-f64 transform of the same kernel the GPU must be no worse than
+    2x the CPU oracle's own fp32 error + 1e-7 of the frame maximum;
+  * dB: <= 2e-4 dB for bins within 20 dB of the frame maximum, <= 1e-2 dB everywhere
+    (a bin 55 dB down has 1/560 of the maximum's magnitude, so a 3e-7 absolute error is 1.5e-3 dB).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pitchvis_amd as P
+from oracle import model_f64 as MF
+from helpers import GEOMS, get_geom, three_regime, white_noise, sine_sweep, mask_to_indices
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALGOS = [P.ALGO_FFT, P.ALGO_BLOCKDFT]
+
+
+def _applicable(v, algo, hop, nf):
+    if algo == P.ALGO_FFT:
+        return True
+    try:
+        v.set_algo(algo)
+        d = torch.zeros(hop * 64 + 40000, device="cuda")
+        o = torch.empty((64, v.n_bins), device="cuda")
+        v.calculate_batch_db_device(d, hop, 64, o, n_lead=40000)
+        torch.cuda.synchronize()
+        return True
+    except P.PvqError as e:
+        if e.status == 7:
+            return False
+        raise
+
+
+def run_gpu(v, pcm, hop, nf, n_lead=0, want_cplx=True):
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm, np.float32)).cuda()
+    d_db = torch.full((nf, v.n_bins), -1.0, device="cuda")
+    d_cx = torch.zeros((nf, v.n_bins, 2), device="cuda") if want_cplx else None
+    v.calculate_batch_db_device(d_pcm, hop, nf, d_db, n_lead=n_lead, d_out_cplx=d_cx)
+    torch.cuda.synchronize()
+    db = d_db.cpu().numpy()
+    cx = d_cx.cpu().numpy().view(np.complex64)[..., 0] if want_cplx else None
+    return db, cx
+
+
+def input_peak(pcm, hop, nf, n_lead, union):
+    """max |x| over the window union of each frame"""
+    a = np.abs(np.asarray(pcm, np.float32))
+    out = np.zeros(nf, np.float32)
+    for f in range(nf):
+        end = n_lead + (f + 1) * hop
+        out[f] = a[max(end - union, 0):end].max()
+    return out
+
+
+def assert_parity(db, cx, wdb, wcx, truth=None, xpeak=None, sr=None):
+    fmax = np.abs(wcx).max(axis=1, keepdims=True)
+    fmax = np.maximum(fmax, 1e-30)
+    well = np.ones(fmax.shape[0], bool)
+    if xpeak is not None:
+        floor = 0.01 * np.sqrt(sr) * np.asarray(xpeak, np.float32)[:, None]
+        well = (fmax >= floor)[:, 0]
+        fmax = np.maximum(fmax, floor)
+    assert (np.abs(cx - wcx) / fmax).max() <= 1e-5
+    if not well.all():  # cancellation-dominated frames: only the scaled bound above and a loose dB bound
+        assert np.abs(db - wdb)[~well].max() <= 0.05
+        db, cx, wdb, wcx, fmax = db[well], cx[well], wdb[well], wcx[well], fmax[well]
+        truth = truth[well] if truth is not None else None
+    strong = np.abs(wcx) >= 1e-1 * fmax
+    rel = np.abs(np.abs(cx) - np.abs(wcx))[strong] / np.abs(wcx)[strong]
+    assert rel.size == 0 or rel.max() <= 1e-5
+    if truth is not None:
+        e_gpu = (np.abs(cx - truth) / fmax).max()
+        e_cpu = (np.abs(wcx - truth) / fmax).max()
+        assert e_gpu <= 2.0 * e_cpu + 1e-7, (e_gpu, e_cpu)
+    top = np.abs(wcx) >= 0.1 * fmax
+    assert np.abs(db - wdb)[top].max(initial=0) <= 2e-4
+    assert np.abs(db - wdb).max(initial=0) <= 1e-2
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("name", list(GEOMS))
+def test_batch_parity_noise(name, algo):
+    pp, op = get_geom(name)
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    hop = 128 if op.sr > 90000 else 256
+    nf, n_lead = 72, 33000
+    if not _applicable(v, algo, hop, nf):
+        pytest.skip("block-DFT path not applicable to this geometry/hop")
+    v.set_algo(algo)
+    pcm = white_noise(n_lead + hop * nf, 0x5EED0001)
+    db, cx = run_gpu(v, pcm, hop, nf, n_lead)
+    assert v.last_algo() == algo
+    wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
+    truth = MF.from_oracle_params(op, values_from=ov).batch_complex(pcm, hop, 8, n_lead=n_lead)
+    assert_parity(db[:8], cx[:8], wdb[:8], wcx[:8], truth)
+    assert_parity(db, cx, wdb, wcx)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_three_regimes_and_stream_start(algo):
+    """silent / clip-branch / shift-branch frames (vqt.rs:939-951), starting from an empty ring
+    buffer (zeros before the stream: the first frames see partly-filled windows)."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    hop, nf = 256, 384
+    if not _applicable(v, algo, hop, nf):
+        pytest.skip("not applicable")
+    v.set_algo(algo)
+    pcm = three_regime(hop * nf, op.sr, 3)
+    db, cx = run_gpu(v, pcm, hop, nf, 0)
+    wdb, wcx = ov.calculate_batch(pcm, hop, nf, want_complex=True)
+    silent = (np.abs(wcx) == 0).all(axis=1)
+    assert silent.sum() > 20
+    assert (db[silent] == 0).all() and (np.abs(cx[silent]) == 0).all()   # exact
+    xp = input_peak(pcm, hop, nf, 0, v.window_union)
+    assert_parity(db[~silent], cx[~silent], wdb[~silent], wcx[~silent], xpeak=xp[~silent], sr=op.sr)
+    raw_min = (10 * np.log10(np.maximum(np.abs(wcx) ** 2, 1e-12)) - 10 * np.log10(0.09)).min(axis=1)
+    assert (raw_min[~silent] > 0).sum() > 20, "shift branch not exercised"
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_sweep_parity(algo):
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    hop, nf = 256, 375  # BASELINE config 1: 2.000 s at 48 kHz
+    if not _applicable(v, algo, hop, nf):
+        pytest.skip("not applicable")
+    v.set_algo(algo)
+    pcm = sine_sweep(hop * nf, op.sr)
+    db, cx = run_gpu(v, pcm, hop, nf, 0)
+    wdb, wcx = ov.calculate_batch(pcm, hop, nf, want_complex=True)
+    xp = input_peak(pcm, hop, nf, 0, v.window_union)
+    assert_parity(db, cx, wdb, wcx, xpeak=xp, sr=op.sr)
+    assert (db.argmax(axis=1)[100:] == wdb.argmax(axis=1)[100:]).all()
+
+
+def test_ragged_and_edge_cases():
+    pp, op = get_geom("serial_22k_180")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    # hop that is not a power of two, single frame, tiny lead, hop > window union, empty batch
+    for hop, nf, n_lead in ((441, 5, 0), (441, 1, 17), (1, 3, 5000), (40000, 2, 123), (256, 0, 0)):
+        pcm = white_noise(n_lead + hop * nf + 1, 21)
+        got = v.calculate_batch_db(pcm, hop, nf, n_lead=n_lead)
+        assert got.shape == (nf, v.n_bins)
+        if nf:
+            want = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead)
+            assert np.abs(got - want).max() <= 1e-2
+            assert v.last_algo() == P.ALGO_FFT or hop in (1, 256)
+
+
+def test_instant_api_matches_reference_semantics():
+    for name in ("default_22k_588", "bench_48k_252"):
+        pp, op = get_geom(name)
+        v = P.Vqt.new(pp, 0)
+        ov = O.OracleVqt(op)
+        x = O.test_create_sines(op, [440.0, 554.37, 82.41])
+        a = v.calculate_vqt_instant_in_db(x)
+        b = ov.calculate_vqt_instant_in_db(x)
+        assert a.shape == (pp.range.n_buckets(),)
+        assert np.abs(a - b).max() <= 1e-2 and np.abs(a - b)[b > b.max() - 20].max() <= 2e-4
+        with pytest.raises(AssertionError):  # vqt.rs:867-871
+            v.calculate_vqt_instant_in_db(x[:-1])
+        from pitchvis_amd import _lib
+        import ctypes as C
+        out = np.zeros(v.n_bins, np.float32)
+        st = _lib.load().pvq_vqt_calculate_instant_db(v._h, x.ctypes.data_as(C.POINTER(C.c_float)), 100,
+                                                      out.ctypes.data_as(C.POINTER(C.c_float)))
+        assert st == _lib.PVQ_ERR_BAD_LENGTH
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_golden_fixtures(algo):
+    z = np.load(os.path.join(G, "bench_48k_252_frames.npz"))
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    hop, nf, n_lead = int(z["hop"]), int(z["n_frames"]), int(z["n_lead"])
+    if not _applicable(v, algo, hop, 64):
+        pytest.skip("not applicable")
+    v.set_algo(algo)
+    for case in ("noise", "regimes"):
+        db, cx = run_gpu(v, z[f"{case}_pcm"], hop, nf, n_lead)
+        keep = np.abs(z[f"{case}_cplx"]).max(axis=1) > 0
+        xp = input_peak(z[f"{case}_pcm"], hop, nf, n_lead, v.window_union)
+        assert_parity(db[keep], cx[keep], z[f"{case}_db"][keep], z[f"{case}_cplx"][keep], xpeak=xp[keep], sr=op.sr)
+    z2 = np.load(os.path.join(G, "default_22k_588_frames.npz"))
+    pp, op = get_geom("default_22k_588")
+    v = P.Vqt.new(pp, 0)
+    got = v.calculate_batch_db(z2["pcm"], int(z2["hop"]), int(z2["n_frames"]))
+    assert np.abs(got - z2["db"]).max() <= 1e-2
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_full_size_properties(algo):
+    """BASELINE config 2 size (65 536 hops of white noise, 48 kHz / 252 bins) through
+    size-independent properties: homogeneity (x2 input => exactly x2 coefficients: scaling by a
+    power of two is exact in fp32 through every linear stage), shift consistency (dropping k hops
+    from the front leaves the later frames bit-identical), determinism, and a spot check of 48
+    scattered frames against the oracle."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    hop, nf = 256, 65536
+    if not _applicable(v, algo, hop, nf):
+        pytest.skip("not applicable")
+    v.set_algo(algo)
+    g = torch.Generator(device="cuda"); g.manual_seed(0x5EED0001)
+    d_pcm = (torch.rand(hop * nf, device="cuda", generator=g) - 0.5) * 0.5
+    d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
+    v.calculate_batch_db_device(d_pcm, hop, nf, d_db, d_out_cplx=d_cx); torch.cuda.synchronize()
+    # determinism
+    d_db2 = torch.empty_like(d_db); d_cx2 = torch.empty_like(d_cx)
+    v.calculate_batch_db_device(d_pcm, hop, nf, d_db2, d_out_cplx=d_cx2); torch.cuda.synchronize()
+    assert torch.equal(d_db, d_db2) and torch.equal(d_cx, d_cx2)
+    # homogeneity
+    v.calculate_batch_db_device(d_pcm * 2.0, hop, nf, d_db2, d_out_cplx=d_cx2); torch.cuda.synchronize()
+    assert torch.equal(d_cx2, d_cx * 2.0)
+    # shift consistency: stream without its first k hops, but carrying them as history
+    k = 4096
+    nf2 = nf - k
+    v.calculate_batch_db_device(d_pcm, hop, nf2, d_db2, n_lead=k * hop, d_out_cplx=d_cx2); torch.cuda.synchronize()
+    assert torch.equal(d_cx2[:nf2], d_cx[k:]) and torch.equal(d_db2[:nf2], d_db[k:])
+    # spot check against the oracle
+    ov = O.OracleVqt(op)
+    pcm = d_pcm.cpu().numpy()
+    rng = np.random.default_rng(1)
+    frames = np.concatenate([[0, 1, 63, 64, nf - 1], rng.integers(65, nf - 1, 43)])
+    db = d_db.cpu().numpy(); cx = d_cx.cpu().numpy().view(np.complex64)[..., 0]
+    for f in frames:
+        end = (f + 1) * hop
+        beg = max(end - op.n_fft, 0)
+        x = np.zeros(op.n_fft, np.float32); x[op.n_fft - (end - beg):] = pcm[beg:end]
+        wcx = ov.calculate_vqt_instant_complex(x)[None]; wdb = ov.calculate_vqt_instant_in_db(x)[None]
+        assert_parity(db[f:f + 1], cx[f:f + 1], wdb, wcx, xpeak=np.array([np.abs(x).max()]), sr=op.sr)
+    assert torch.isfinite(d_db).all() and (d_db >= 0).all() and (d_db <= 60.0).all()

@@ -1,0 +1,119 @@
+"""GPU peak / note detection (K4) against the oracle's restatement of find_peaks 0.1.5 +
+enhance_peaks_continuous + promote_bass_peaks_with_harmonics.
+
+Bar: peak-bin indices BIT-IDENTICAL when both sides see the same dB frame; continuous centre
+within 1e-4 bins (device expf/log2f differ from glibc by <= 2 ulp at centres of ~200) and size
+within 2e-3 dB (the size is interpolated at the centre: its error is the centre error times the local
+slope of up to ~10 dB/bin).
+End to end (GPU dB -> GPU peaks vs CPU dB -> CPU peaks) the sets are identical except in frames
+where a dB value sits within the dB parity tolerance of a threshold or a tie; those frames are
+counted and listed, not hidden."""
+import numpy as np
+import pytest
+
+import oracle as O
+import pitchvis_amd as P
+from helpers import get_geom, white_noise, mask_to_indices
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _frames(op, nf, seed, hop=2048):
+    ov = O.OracleVqt(op)
+    rng = np.random.default_rng(seed)
+    n = hop * nf + 30000
+    t = np.arange(n) / op.sr
+    pcm = white_noise(n, seed, amp=0.05).astype(np.float64)
+    for k in rng.integers(0, op.octaves * 12 - 6, 6):
+        pcm += 0.08 * np.sin(2 * np.pi * op.min_freq * 2 ** (k / 12.0) * t * (1 + 0.002 * rng.standard_normal()))
+    return ov.calculate_batch(pcm.astype(np.float32), hop, nf, n_lead=30000)
+
+
+@pytest.mark.parametrize("name", ["bench_48k_252", "default_22k_588", "hires_96k_360", "serial_22k_180"])
+def test_peaks_bit_identical_on_same_frames(name):
+    pp, op = get_geom(name)
+    v = P.Vqt.new(pp, 0)
+    db = np.concatenate([_frames(op, 96, 5), np.abs(np.random.default_rng(3).normal(0, 9, (160, v.n_bins))).astype(np.float32)])
+    mask, count, center, size = v.analyze_batch(db, max_peaks=96)
+    for f in range(db.shape[0]):
+        wp, wce, wsz = O.analyze_frame(db[f], op.min_freq, op.octaves, op.buckets_per_octave)
+        gp = mask_to_indices(mask[f], v.n_bins)
+        assert np.array_equal(gp, wp), (name, f)
+        assert count[f] == wp.size
+        k = wp.size
+        assert np.abs(center[f, :k] - wce).max(initial=0) <= 1e-4
+        assert np.abs(size[f, :k] - wsz).max(initial=0) <= 2e-3
+
+
+def test_crafted_plateaus_edges_and_split():
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    n = v.n_bins
+    frames = np.zeros((6, n), np.float32)
+    frames[0, [0, n - 1]] = 30.0                      # edges are never peaks
+    frames[1, 50:53] = 20.0                           # plateau -> middle
+    frames[1, 100:102] = 12.0                         # even plateau
+    frames[2, [1, 2, 3]] = [9.0, 9.5, 9.0]            # min_bin = 2
+    frames[2, 1] = 0.0; frames[2, 2] = 9.0; frames[2, 3] = 0.0
+    frames[3, 28] = 6.0; frames[3, 30] = 6.0; frames[3, 60] = 10.0; frames[3, 90] = 3.99  # split at 28
+    frames[4] = 5.0                                   # flat
+    frames[5] = np.linspace(0, 40, n)                 # monotone
+    fa = v.analyze_frames(frames)
+    for f in range(frames.shape[0]):
+        wp, _, _ = O.analyze_frame(frames[f], op.min_freq, op.octaves, op.buckets_per_octave)
+        assert sorted(fa[f].peaks) == list(wp), f
+    assert sorted(fa[1].peaks) == [51, 101] and sorted(fa[3].peaks) == [28, 60] and not fa[0].peaks
+
+
+def test_vqt_close_frequencies_end_to_end_on_gpu():
+    """reference lib.rs:16-48 through the GPU: two sines a semitone apart => exactly 2 peaks."""
+    pp, op = get_geom("default_22k_588")
+    v = P.Vqt.new(pp, 0)
+    sub = 30
+    stim = []
+    for i in range(int(2.6 * sub), op.octaves * sub - sub // 2):
+        ln = np.float32(i) / np.float32(sub)
+        f1 = np.float32(op.min_freq) * np.float32(2.0) ** ln
+        f2 = np.float32(op.min_freq) * np.float32(2.0) ** (ln + np.float32(1.0 / 12.0))
+        stim.append(O.test_create_sines(op, [f1, f2]))
+    pcm = np.concatenate(stim)
+    db = v.calculate_batch_db(pcm, op.n_fft, len(stim))       # one n_fft buffer per frame
+    horizon_ms = (70.0 * (1.5 - 0.5 * (np.arange(v.n_bins, dtype=np.float32) / op.buckets_per_octave / op.octaves)) * 0.6).astype(np.int64)
+    alpha = (1.0 - np.exp(-2.0 * 1.1 / (horizon_ms / 1000.0))).astype(np.float32)
+    fa = v.analyze_frames((db * alpha[None, :]).astype(np.float32))
+    assert [len(f.peaks) for f in fa] == [2] * len(stim)
+
+
+def test_end_to_end_peak_sets_with_near_threshold_accounting():
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    hop, nf, n_lead = 256, 1500, 20000
+    rng = np.random.default_rng(8)
+    n = n_lead + hop * nf
+    t = np.arange(n) / op.sr
+    pcm = white_noise(n, 8, amp=0.25).astype(np.float64)
+    for k in (12, 19, 31, 40, 47):
+        pcm += 0.1 * np.sin(2 * np.pi * 55.0 * 2 ** (k / 12.0) * t)
+    pcm = pcm.astype(np.float32)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_db = torch.empty((nf, v.n_bins), device="cuda")
+    words = (v.n_bins + 31) // 32
+    d_mask = torch.zeros((nf, words), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt, n_lead=n_lead)
+    torch.cuda.synchronize()
+    mask = d_mask.cpu().numpy().view(np.uint32)
+    gdb = d_db.cpu().numpy()
+    wdb = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead)
+    differing = []
+    for f in range(nf):
+        gp = mask_to_indices(mask[f], v.n_bins)
+        # the peak logic itself must be exact on the GPU's own frame ...
+        assert np.array_equal(gp, O.find_peaks_split(gdb[f], 36)), f
+        # ... and end to end the sets agree unless a threshold is within the dB tolerance
+        if not np.array_equal(gp, O.find_peaks_split(wdb[f], 36)):
+            differing.append(f)
+    print(f"end-to-end peak sets differ in {len(differing)} of {nf} frames (near-threshold): {differing[:20]}")
+    assert len(differing) <= nf // 100
