@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — VQT frames/s on MI355X (BASELINE.json metric), with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--algo auto|fft|blockdft]
+
+One "step" = one pass of the hot path (PCM -> per-window-group spectra -> sparse kernel products
+-> frame-relative dB -> peak/note detection) over one batch of synthetic input resident in HBM:
+BASELINE.json configs[1], "65 536-hop batch of 48 kHz mono white noise", geometry
+VqtParameters{sr 48000, n_fft 32768, range{55 Hz, 7 oct, 36 bins/oct}, sparsity 0.999, Q 1.6,
+gamma 7.68}, hop 256, 252 bins, fp32.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the hop stream shards into
+contiguous frame ranges, one per rank, each carrying its window-union halo; kernel tables are
+replicated; there is no collective on the data path.  Weak scaling: every rank
+processes F frames, value = N*F*K / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# SURVEY.md §8(d), BASELINE.md §2 — per-frame algorithmic work of the 48 kHz / 7x36 geometry
+F_ALG_FLOP_PER_FRAME = 1.12e6       # 5 rFFTs (2.5 N log2 N) + 8 flop per kernel non-zero + dB/peaks
+B_ALG_BYTES_PER_FRAME = 2064.0      # hop*4 new input + 252*4 dB out + 8*4 peak mask
+PEAK_FP32_TFLOPS = 157.3            # MI355X fp32 dense MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0               # HBM3E spec peak
+
+SR, HOP, N_BINS = 48000.0, 256, 252
+
+
+def _cpu_worker(args):
+    """one oracle instance per worker over a disjoint frame range (train.rs:146-155 pattern)"""
+    seed, n_frames = args
+    import numpy as np
+    import oracle as O
+    op = O.OracleParams(sr=SR, min_freq=55.0, octaves=7, buckets_per_octave=36)
+    ov = O.OracleVqt(op)
+    rng = np.random.default_rng(seed)
+    n_lead = 16384
+    pcm = ((rng.random(n_lead + n_frames * HOP, dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    t0 = time.perf_counter()
+    db = ov.calculate_batch(pcm, HOP, n_frames, n_lead=n_lead)
+    n_peaks = 0
+    for f in range(n_frames):
+        idx, _, _ = O.analyze_frame(db[f], 55.0, 7, 36)
+        n_peaks += idx.size
+    return time.perf_counter() - t0, n_peaks
+
+
+def cpu_baseline():
+    """The CPU restatement of the reference path (oracle, kind "port") on this host's cores,
+    bounded sample: `cores` workers x 2048 frames of the same workload (white noise, 48 kHz/252)."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import oracle as O
+    O.build()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    per = 2048
+    # single thread first
+    t1, _ = _cpu_worker((1000, per))
+    with cf.ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
+        list(ex.map(_cpu_worker, [(1, 8)] * cores))  # start the workers, load the library
+        t0 = time.perf_counter()
+        res = list(ex.map(_cpu_worker, [(2000 + i, per) for i in range(cores)]))
+        wall = time.perf_counter() - t0
+    return {
+        "value": round(cores * per / wall, 1),
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cores} workers x {per} frames (hop 256, 48 kHz/252 bins, white noise), VQT+dB+peaks, "
+                  f"oracle/pvq_oracle.c -O2; 1 core: {per / t1:.0f} frames/s",
+        "value_1core": round(per / t1, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=65536, help="frames (hops) per GPU per step")
+    ap.add_argument("--algo", default="auto", choices=["auto", "fft", "blockdft"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+
+    # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.build()
+    import pitchvis_amd as P
+    from pitchvis_amd.sharding import plan_shard
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+
+    params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, 7, 36))
+    vqt = P.Vqt.new(params, device=local_rank)
+    vqt.set_algo({"auto": P.ALGO_AUTO, "fft": P.ALGO_FFT, "blockdft": P.ALGO_BLOCKDFT}[args.algo])
+    assert vqt.n_bins == N_BINS
+
+    # this rank's shard of a world*F-frame stream: its hops plus the window-union halo
+    F = args.frames
+    shard = plan_shard(world * F, HOP, vqt.window_union, rank, world)
+    n_local = shard.sample_end - shard.sample_begin
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x5EED0001 + rank)
+    d_pcm = (torch.rand(n_local, device="cuda", generator=g) - 0.5) * 0.5   # uniform [-0.25, 0.25)
+    d_db = torch.empty((F, N_BINS), device="cuda", dtype=torch.float32)
+    words = (N_BINS + 31) // 32
+    max_peaks = 64
+    d_mask = torch.zeros((F, words), device="cuda", dtype=torch.int32)
+    d_cnt = torch.zeros(F, device="cuda", dtype=torch.int32)
+    d_ctr = torch.zeros((F, max_peaks), device="cuda", dtype=torch.float32)
+    d_sz = torch.zeros((F, max_peaks), device="cuda", dtype=torch.float32)
+
+    def step():
+        vqt.vqt_analyze_batch_device(d_pcm, HOP, shard.n_frames, d_db, d_mask, d_cnt, d_ctr, d_sz, max_peaks,
+                                     n_lead=shard.n_lead)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    vqt.set_profiling(True)   # HIP events around every kernel launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = vqt.last_kernel_ms()
+    vqt.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_frames = world * F * args.steps
+        value = total_frames / dt
+        # sanity: the output is real (not skipped work)
+        assert torch.isfinite(d_db).all() and float(d_db.max()) > 0.0 and int(d_cnt.sum()) > 0
+        dom = max(((k, v) for k, v in kernel_ms.items() if k != "peaks_frames"), key=lambda kv: kv[1])
+        dom_s = dom[1] * 1e-3
+        tflops = F_ALG_FLOP_PER_FRAME * F / dom_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == F:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "vqt_frames_per_sec",
+            "value": round(value, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: {F}-hop batch of 48 kHz mono white noise per GPU, hop 256, "
+                            "VqtParameters{sr 48000, n_fft 32768, 55 Hz, 7 oct x 36 = 252 bins, sparsity 0.999, "
+                            "Q 1.6, gamma 7.68}; PCM -> VQT dB frames -> peaks (mask+count+continuous)",
+                "frames_per_gpu_per_step": F,
+                "hop": HOP,
+                "n_bins": N_BINS,
+                "algo": {P.ALGO_FFT: "fft", P.ALGO_BLOCKDFT: "blockdft"}.get(vqt.last_algo(), "auto"),
+                "sharding": f"frames x{world}, halo {vqt.window_union - HOP} samples, no collective",
+            },
+            "roofline": {
+                # binding roof of this path is fp32 arithmetic (dense fp32 MFMA peak = fp32 vector peak);
+                # the HBM view required by BASELINE.json is given alongside (<<1 %).
+                "bound": "mfma",
+                "kernel": dom[0],
+                "achieved": round(tflops, 3),
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(tflops / PEAK_FP32_TFLOPS, 5),
+                "traffic": traffic,
+                "alg_flop_per_frame": F_ALG_FLOP_PER_FRAME,
+                "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms.items()},
+                "hbm": {
+                    "achieved": round(B_ALG_BYTES_PER_FRAME * F / dom_s / 1e9, 3),
+                    "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s",
+                    "frac": round(B_ALG_BYTES_PER_FRAME * F / dom_s / 1e9 / PEAK_HBM_GBS, 6),
+                    "alg_bytes_per_frame": B_ALG_BYTES_PER_FRAME,
+                },
+            },
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -600,11 +600,9 @@ Vqt::~Vqt() {
         if (ws_pcm_) (void)hipFree(ws_pcm_);
         if (ws_out_) (void)hipFree(ws_out_);
         if (ws_misc_) (void)hipFree(ws_misc_);
-        if (ev_created_)
-            for (int s = 0; s < N_SLOTS; ++s) {
-                (void)hipEventDestroy(ev_[s][0]);
-                (void)hipEventDestroy(ev_[s][1]);
-            }
+        for (int s = 0; s < N_SLOTS; ++s)
+            for (int k = 0; k < 2; ++k)
+                for (hipEvent_t e : ev_[s][k]) (void)hipEventDestroy(e);
     }
 }
 
@@ -628,33 +626,44 @@ pvq_status Vqt::ensure_workspace(void** ptr, size_t* cap, size_t bytes) {
     return PVQ_OK;
 }
 
+void Vqt::set_profiling(bool on) {
+    profiling_ = on;
+    for (int s = 0; s < N_SLOTS; ++s) ev_count_[s] = 0;
+}
+
 void Vqt::slot_begin(int slot, hipStream_t s) {
-    if (!profiling_) return;
-    if (!ev_created_) {
-        for (int i = 0; i < N_SLOTS; ++i) {
-            (void)hipEventCreate(&ev_[i][0]);
-            (void)hipEventCreate(&ev_[i][1]);
-        }
-        ev_created_ = true;
+    if (!profiling_ || ev_count_[slot] >= kMaxTimedLaunches) return;
+    const int i = ev_count_[slot];
+    if ((int)ev_[slot][0].size() <= i) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        ev_[slot][0].push_back(a);
+        ev_[slot][1].push_back(b);
     }
-    (void)hipEventRecord(ev_[slot][0], s);
-    ev_used_[slot] = true;
+    (void)hipEventRecord(ev_[slot][0][i], s);
 }
 void Vqt::slot_end(int slot, hipStream_t s) {
-    if (!profiling_) return;
-    (void)hipEventRecord(ev_[slot][1], s);
+    if (!profiling_ || ev_count_[slot] >= kMaxTimedLaunches) return;
+    (void)hipEventRecord(ev_[slot][1][ev_count_[slot]], s);
+    ++ev_count_[slot];
 }
 
 uint32_t Vqt::last_kernel_ms(float* out, uint32_t cap) {
     uint32_t n = 0;
     for (int s = 0; s < N_SLOTS && (uint32_t)s < cap; ++s) {
         out[s] = -1.0f;
-        if (ev_created_ && ev_used_[s]) {
-            if (hipEventSynchronize(ev_[s][1]) == hipSuccess) {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, ev_[s][0], ev_[s][1]) == hipSuccess) out[s] = ms;
+        double sum = 0.0;
+        int ok = 0;
+        for (int i = 0; i < ev_count_[s]; ++i) {
+            if (hipEventSynchronize(ev_[s][1][i]) != hipSuccess) continue;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev_[s][0][i], ev_[s][1][i]) == hipSuccess) {
+                sum += ms;
+                ++ok;
             }
         }
+        if (ok) out[s] = (float)(sum / ok);
         n = s + 1;
     }
     return n;
@@ -713,7 +722,6 @@ pvq_status Vqt::calculate_batch_db_device(const float* d_pcm, size_t n_lead, siz
         return PVQ_ERR_INVALID_ARG;
     }
     PVQ_HIP(hipSetDevice(device_id_));
-    for (int s = 0; s < N_SLOTS; ++s) ev_used_[s] = false;
     bool use_block = false;
     if (algo_ == PVQ_ALGO_BLOCKDFT) {
         if (!blockdft_applicable(hop)) {

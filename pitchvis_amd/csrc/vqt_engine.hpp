@@ -55,7 +55,9 @@ class Vqt {
 
     void set_algo(pvq_algo a) { algo_ = a; }
     pvq_algo last_algo() const { return last_algo_; }
-    void set_profiling(bool on) { profiling_ = on; }
+    // HIP-event timing of every kernel launch (per slot) on the stream it is launched on.
+    // Enabling resets the statistics; last_kernel_ms reports the mean per launch since then.
+    void set_profiling(bool on);
     uint32_t last_kernel_ms(float* out, uint32_t cap);
 
     enum KernelSlot { SLOT_FFT_FRAMES = 0, SLOT_BLOCKDFT_GEMM = 1, SLOT_BLOCKDFT_COMBINE = 2, SLOT_PEAKS = 3, N_SLOTS = 4 };
@@ -80,9 +82,9 @@ class Vqt {
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
     bool profiling_ = false;
-    hipEvent_t ev_[N_SLOTS][2] = {};
-    bool ev_used_[N_SLOTS] = {};
-    bool ev_created_ = false;
+    static constexpr int kMaxTimedLaunches = 512;
+    std::vector<hipEvent_t> ev_[N_SLOTS][2];  // event pool, grown on demand
+    int ev_count_[N_SLOTS] = {};              // launches recorded since profiling was enabled
     // grow-only workspaces for the host-pointer wrappers
     void* ws_pcm_ = nullptr;  size_t ws_pcm_cap_ = 0;
     void* ws_out_ = nullptr;  size_t ws_out_cap_ = 0;
