@@ -163,6 +163,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kernel_ms = vqt.last_kernel_ms()
+    kernel_n = vqt.last_kernel_launches()
+    fpl = vqt.last_frames_per_launch()
     vqt.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -174,15 +176,17 @@ def main():
         value = total_frames / dt
         # sanity: the output is real (not skipped work)
         assert torch.isfinite(d_db).all() and float(d_db.max()) > 0.0 and int(d_cnt.sum()) > 0
-        dom = max(((k, v) for k, v in kernel_ms.items() if k != "peaks_frames"), key=lambda kv: kv[1])
+        # dominant kernel = largest total GPU time; one launch of it processes `fpl` frames
+        dom = max(kernel_ms.items(), key=lambda kv: kv[1] * kernel_n.get(kv[0], 1))
         dom_s = dom[1] * 1e-3
-        tflops = F_ALG_FLOP_PER_FRAME * F / dom_s / 1e12
+        tflops = F_ALG_FLOP_PER_FRAME * fpl / dom_s / 1e12
+        gpu_ms_per_step = sum(kernel_ms[k] * kernel_n.get(k, 0) for k in kernel_ms) / args.steps
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == F:
+                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == fpl:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -220,12 +224,18 @@ def main():
                 "frac": round(tflops / PEAK_FP32_TFLOPS, 5),
                 "traffic": traffic,
                 "alg_flop_per_frame": F_ALG_FLOP_PER_FRAME,
+                "frames_per_launch": fpl,
                 "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms.items()},
+                "launches_per_step": {k: kernel_n.get(k, 0) // args.steps for k in kernel_ms},
+                "gpu_ms_per_step_all_kernels": round(gpu_ms_per_step, 4),
+                # whole path (all kernels of a step) against the same fp32 roof
+                "path_tflops": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12, 3),
+                "path_frac": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 5),
                 "hbm": {
-                    "achieved": round(B_ALG_BYTES_PER_FRAME * F / dom_s / 1e9, 3),
+                    "achieved": round(B_ALG_BYTES_PER_FRAME * fpl / dom_s / 1e9, 3),
                     "peak": PEAK_HBM_GBS,
                     "unit": "GB/s",
-                    "frac": round(B_ALG_BYTES_PER_FRAME * F / dom_s / 1e9 / PEAK_HBM_GBS, 6),
+                    "frac": round(B_ALG_BYTES_PER_FRAME * fpl / dom_s / 1e9 / PEAK_HBM_GBS, 6),
                     "alg_bytes_per_frame": B_ALG_BYTES_PER_FRAME,
                 },
             },

@@ -175,10 +175,15 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt *v, const float *d_pcm, size_t n
 
 /* timing hook for bench.py: elapsed GPU milliseconds of the dominant kernel launches of the
  * last batch call, measured with HIP events on the stream the kernels were launched on.
- * Enable with pvq_vqt_set_profiling(v, 1); reading synchronises the stream. */
+ * Enable with pvq_vqt_set_profiling(v, 1) (resets the statistics); reading synchronises. */
 pvq_status pvq_vqt_set_profiling(pvq_vqt *v, int enable);
 /* out_ms[i] for kernel slot i (see pvq_vqt_kernel_name); returns the number of slots filled */
 uint32_t pvq_vqt_last_kernel_ms(pvq_vqt *v, float *out_ms, uint32_t capacity);
+/* out_n[i] = launches of kernel slot i recorded since profiling was enabled (a batch call may
+ * launch a kernel once per sub-batch); out_ms above is the mean per launch */
+uint32_t pvq_vqt_last_kernel_launches(pvq_vqt *v, uint32_t *out_n, uint32_t capacity);
+/* frames one launch of the frame kernels processed in the last batch call (the sub-batch size) */
+uint32_t pvq_vqt_last_frames_per_launch(const pvq_vqt *v);
 const char *pvq_vqt_kernel_name(uint32_t slot);
 
 #ifdef __cplusplus

@@ -350,6 +350,15 @@ class Vqt:
         _check(self._L.pvq_vqt_set_profiling(self._h, 1 if on else 0))
 
     def last_kernel_ms(self) -> dict:
+        """mean GPU ms per launch of each kernel since set_profiling(True)"""
         buf = (C.c_float * 8)()
         n = self._L.pvq_vqt_last_kernel_ms(self._h, buf, 8)
         return {self._L.pvq_vqt_kernel_name(i).decode(): buf[i] for i in range(n) if buf[i] >= 0.0}
+
+    def last_kernel_launches(self) -> dict:
+        buf = (C.c_uint32 * 8)()
+        n = self._L.pvq_vqt_last_kernel_launches(self._h, buf, 8)
+        return {self._L.pvq_vqt_kernel_name(i).decode(): int(buf[i]) for i in range(n) if buf[i] > 0}
+
+    def last_frames_per_launch(self) -> int:
+        return int(self._L.pvq_vqt_last_frames_per_launch(self._h))

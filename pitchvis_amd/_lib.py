@@ -16,7 +16,7 @@ EXPORTS = [
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
-    "pvq_vqt_kernel_name",
+    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch",
 ]
 
 PVQ_OK = 0
@@ -110,6 +110,8 @@ def load():
     L.pvq_vqt_analyze_batch_device.restype = C.c_int
     L.pvq_vqt_set_profiling.argtypes = [vp, C.c_int]; L.pvq_vqt_set_profiling.restype = C.c_int
     L.pvq_vqt_last_kernel_ms.argtypes = [vp, fp, C.c_uint32]; L.pvq_vqt_last_kernel_ms.restype = C.c_uint32
+    L.pvq_vqt_last_kernel_launches.argtypes = [vp, up, C.c_uint32]; L.pvq_vqt_last_kernel_launches.restype = C.c_uint32
+    L.pvq_vqt_last_frames_per_launch.argtypes = [vp]; L.pvq_vqt_last_frames_per_launch.restype = C.c_uint32
     L.pvq_vqt_kernel_name.argtypes = [C.c_uint32]; L.pvq_vqt_kernel_name.restype = C.c_char_p
     _lib = L
     return L

@@ -216,11 +216,9 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt* v, const float* d_pcm, size_t n
                                         uint32_t* d_peak_count, float* d_center, float* d_size, uint32_t max_peaks,
                                         void* stream) {
     if (!v) return null_handle();
-    pvq_status st = v->impl->calculate_batch_db_device(d_pcm, n_lead, hop, n_frames, d_out_db, nullptr,
-                                                       static_cast<hipStream_t>(stream));
-    if (st != PVQ_OK) return st;
-    return v->impl->analyze_batch_device(d_out_db, n_frames, to_cpp(a), d_peak_mask, d_peak_count, d_center, d_size,
-                                         max_peaks, static_cast<hipStream_t>(stream));
+    return v->impl->vqt_analyze_batch_device(d_pcm, n_lead, hop, n_frames, to_cpp(a), d_out_db, d_peak_mask,
+                                             d_peak_count, d_center, d_size, max_peaks,
+                                             static_cast<hipStream_t>(stream));
 }
 
 pvq_status pvq_vqt_set_profiling(pvq_vqt* v, int enable) {
@@ -232,6 +230,11 @@ uint32_t pvq_vqt_last_kernel_ms(pvq_vqt* v, float* out_ms, uint32_t capacity) {
     if (!v || !out_ms) return 0;
     return v->impl->last_kernel_ms(out_ms, capacity);
 }
+uint32_t pvq_vqt_last_kernel_launches(pvq_vqt* v, uint32_t* out_n, uint32_t capacity) {
+    if (!v || !out_n) return 0;
+    return v->impl->last_kernel_launches(out_n, capacity);
+}
+uint32_t pvq_vqt_last_frames_per_launch(const pvq_vqt* v) { return v ? v->impl->last_frames_per_launch() : 0; }
 const char* pvq_vqt_kernel_name(uint32_t slot) { return pvq::Vqt::slot_name(slot); }
 
 }  // extern "C"

