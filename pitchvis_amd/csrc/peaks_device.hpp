@@ -91,7 +91,7 @@ __device__ __forceinline__ bool pk_prom_ok_wave(const float (&v)[NK], int n, int
 }
 
 // enhance + promote for one peak (see refine note in vqt_engine.hip)
-__device__ inline void pk_refine(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
+__device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
 #pragma clang fp contract(off)
     const int nb = a.n_bins;
     const float bpo = (float)a.bpo;
@@ -174,6 +174,8 @@ __device__ inline void pk_distance_filter(const float* x, int n, const uint8_t* 
     }
 }
 
+// x: the frame's dB values in LDS (n_bins <= 64*NK floats, already visible to the whole wave);
+// scratch: peaks_scratch_bytes() bytes of LDS private to this wave.  Called by all 64 lanes.
 template <int NK>
 __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
                                               int lane) {
@@ -262,15 +264,6 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
             a.size[frame * a.max_peaks + sidx] = sz;
         }
     }
-}
-
-// x: the frame's dB values in LDS (n_bins floats, already visible to the whole wave);
-// scratch: peaks_scratch_bytes() bytes of LDS private to this wave.  Called by all 64 lanes.
-__device__ inline void peaks_wave(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a, int lane) {
-    if (a.n_bins <= 256)
-        peaks_wave_nk<4>(x, scratch, frame, a, lane);
-    else
-        peaks_wave_nk<16>(x, scratch, frame, a, lane);
 }
 
 }  // namespace pvq

@@ -36,15 +36,17 @@ namespace pvq {
         }                                                                                          \
     } while (0)
 
-constexpr int GM_BM = 128;  // blocks (rows of P) per workgroup
-constexpr int GM_BN = 64;   // real columns per workgroup = 32 complex spectrum columns
-constexpr int GM_BK = 32;
+constexpr int GM_BN = 64;   // granularity of the column tiling: 64 floats = 32 complex spectrum columns
 constexpr int CB_T = 64;    // frames per combine workgroup
 constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 64;
 constexpr int CB_MAX_R = CB_T + CB_MAX_NB - 1;  // rows of P a combine workgroup stages
 constexpr int DT_FB = 4;    // frames per dots workgroup
-constexpr size_t kChunkFrames = 8192;  // frames per sub-batch: P and X of one chunk stay in the Infinity Cache
+static size_t chunk_frames() {  // frames per sub-batch: P and X of one chunk should stay in the Infinity Cache
+    const char* e = getenv("PVQ_CHUNK_FRAMES");  // developer knob
+    const long v = e ? atol(e) : 16384;
+    return (size_t)(v >= 64 ? v : 16384);
+}
 
 struct BlockGroup {
     int nb;         // hop blocks per window
@@ -72,6 +74,7 @@ struct BlockDftTables {
     float2* d_ell_val = nullptr;   // [ell_len][n_bins_pad]
     uint16_t* d_ell_col = nullptr; // X column | 0x8000 (conj)
     uint16_t* d_row_len = nullptr; // [n_bins_pad]
+    uint16_t* d_row_bin = nullptr; // [n_bins_pad] permuted slot -> bin
     float* d_P = nullptr;  size_t p_cap = 0;   // workspace
     float2* d_X = nullptr; size_t x_cap = 0;
 };
@@ -86,6 +89,7 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_ell_val) (void)hipFree(t->d_ell_val);
     if (t->d_ell_col) (void)hipFree(t->d_ell_col);
     if (t->d_row_len) (void)hipFree(t->d_row_len);
+    if (t->d_row_bin) (void)hipFree(t->d_row_bin);
     if (t->d_P) (void)hipFree(t->d_P);
     if (t->d_X) (void)hipFree(t->d_X);
     delete t;
@@ -97,77 +101,127 @@ void free_blockdft_tables(BlockDftTables* t) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
-    const float* pcm;
-    long long n_samples;
+    const float* pcm_base;    // rebased per launch so that byte offsets fit 32 bits
+    unsigned pcm_bytes;       // bytes readable from pcm_base (hardware bounds check: beyond -> 0)
     const float* E;
-    int ld;            // Ntot
+    int ld;                   // Ntot
     float* P;
-    int n_rows;        // rows of P to produce
-    int K;             // hop
-    const long long* tile_s;  // per column tile: window begin relative to the n_fft buffer end (w0 - n_fft)
-    long long base;           // pcm index of the end of frame 0 of this launch (n_lead + hop + chunk offset)
+    int n_rows;               // rows of P to produce
+    int K;                    // hop
+    const long long* tile_s;  // per 64-float column tile: window begin relative to the n_fft buffer end (w0 - n_fft)
+    long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
 };
 
-__global__ __launch_bounds__(256) void blockdft_gemm(GemmArgs a) {
-    __shared__ float As[2][GM_BM][GM_BK + 1];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK][GM_BN];
+// BM x BN output tile, BK k-step, WM x WN waves, each wave (BM/WM) x (BN/WN) as TM x TN 32x32 MFMA tiles.
+// A (the PCM stream seen as [block][hop]) is fetched with raw buffer loads: samples before the
+// stream start or past its end come back as 0 from the hardware range check, no per-element compares.
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_PER = BM * BK / NT;            // dwords of A per thread per k-step
+    constexpr int A_ROWS_PER_PASS = NT / BK;
+    constexpr int B_PER = BK * BN / 4 / NT;        // float4 of B per thread per k-step
+    constexpr int B_ROWS_PER_PASS = NT * 4 / BN;
+    static_assert(A_PER >= 1 && B_PER >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
+    __shared__ float As[2][BM][BK + 1];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
-    const long long s = a.base + a.tile_s[nt];
-    const int j0 = mt * GM_BM;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int j0 = mt * BM;
+    const int wm = wave / WN, wn = wave % WN;
+    // every 64-float tile inside this BN-wide tile belongs to the same group (groups are padded to BN)
+    const long long s = a.base + a.tile_s[nt * (BN / 64)];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
 
-    // global -> register staging
-    float ra[16];
-    float4 rb[2];
-    const int a_row = tid >> 5, a_col = tid & 31;          // + 8*i rows
-    const int b_row = tid >> 4, b_col = (tid & 15) * 4;    // + 16*i rows
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const long long gi = s + (long long)(j0 + a_row + 8 * i) * a.K + k0 + a_col;
-            ra[i] = (gi >= 0 && gi < a.n_samples) ? a.pcm[gi] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            rb[i] = *reinterpret_cast<const float4*>(a.E + (size_t)(k0 + b_row + 16 * i) * a.ld + nt * GM_BN + b_col);
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) As[buf][a_row + 8 * i][a_col] = ra[i];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Bs[buf][b_row + 16 * i][b_col]) = rb[i];
-    };
+    float ra[A_PER];
+    float4 rb[B_PER];
+    const int a_row = tid / BK, a_col = tid % BK;
+    const int b_row = (tid * 4) / BN, b_col = (tid * 4) % BN;
+    // byte offset of A[j0 + a_row][a_col]; negative indices wrap to huge unsigned offsets -> out of range -> 0
+    const unsigned a_off0 = (unsigned)((s + (long long)(j0 + a_row) * a.K + a_col) * 4ll);
+    const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
+    const float* e_ptr = a.E + (size_t)b_row * a.ld + (size_t)nt * BN + b_col;
 
-    f32x16 acc0 = {0}, acc1 = {0};
-    const int n_iter = a.K / GM_BK;
-    load_tile(0);
-    store_tile(0);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+#define PVQ_GEMM_LOAD(k0)                                                                                      \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) ra[i] = __builtin_bit_cast(                          \
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
+        _Pragma("unroll") for (int i = 0; i < B_PER; ++i) rb[i] =                                              \
+            *reinterpret_cast<const float4*>(e_ptr + (size_t)((k0) + i * B_ROWS_PER_PASS) * a.ld);             \
+    }
+#define PVQ_GEMM_STORE(buf)                                                                                    \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) As[buf][a_row + i * A_ROWS_PER_PASS][a_col] = ra[i]; \
+        _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                                      \
+            *reinterpret_cast<float4*>(&Bs[buf][b_row + i * B_ROWS_PER_PASS][b_col]) = rb[i];                  \
+    }
+
+    const int n_iter = a.K / BK;
+    PVQ_GEMM_LOAD(0);
+    PVQ_GEMM_STORE(0);
     __syncthreads();
+    const int ar = wm * (BM / WM) + (lane & 31), kh = lane >> 5, bc = wn * (BN / WN) + (lane & 31);
     for (int it = 0; it < n_iter; ++it) {
         const int buf = it & 1;
-        if (it + 1 < n_iter) load_tile((it + 1) * GM_BK);
-        const int ar = wm * 64 + (lane & 31), kh = lane >> 5, bc = wn * 32 + (lane & 31);
+        if (it + 1 < n_iter) PVQ_GEMM_LOAD((it + 1) * BK);
 #pragma unroll
-        for (int kk = 0; kk < GM_BK / 2; ++kk) {
-            const float a0 = As[buf][ar][2 * kk + kh];
-            const float a1 = As[buf][ar + 32][2 * kk + kh];
-            const float b = Bs[buf][2 * kk + kh][bc];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[buf][ar + 32 * i][2 * kk + kh];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][2 * kk + kh][bc + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < n_iter) store_tile(buf ^ 1);
+        if (it + 1 < n_iter) PVQ_GEMM_STORE(buf ^ 1);
         __syncthreads();
     }
+#undef PVQ_GEMM_LOAD
+#undef PVQ_GEMM_STORE
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-    const int col = nt * GM_BN + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int g0 = j0 + wm * 64 + row;
-        if (g0 < a.n_rows) a.P[(size_t)g0 * a.ld + col] = acc0[r];
-        if (g0 + 32 < a.n_rows) a.P[(size_t)(g0 + 32) * a.ld + col] = acc1[r];
-    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nt * BN + wn * (BN / WN) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = j0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a.n_rows) a.P[(size_t)row * a.ld + col] = acc[i][j][r];
+            }
+        }
+}
+
+struct GemmVariant {
+    int bm, bn;
+    void (*kernel)(GemmArgs);
+    int threads;
+};
+static const GemmVariant kGemmVariants[] = {
+    {128, 64, blockdft_gemm<128, 64, 32, 2, 2>, 256},
+    {128, 128, blockdft_gemm<128, 128, 32, 2, 2>, 256},
+    {128, 64, blockdft_gemm<128, 64, 16, 2, 2>, 256},
+    {256, 64, blockdft_gemm<256, 64, 16, 4, 1>, 256},
+    {128, 128, blockdft_gemm<128, 128, 16, 2, 2>, 256},
+    {256, 128, blockdft_gemm<256, 128, 16, 4, 2>, 512},
+};
+static int gemm_variant_index() {
+    const char* e = getenv("PVQ_GEMM_VARIANT");  // developer knob; the default is the measured best
+    int v = e ? atoi(e) : 2;
+    if (v < 0 || v >= (int)(sizeof(kGemmVariants) / sizeof(kGemmVariants[0]))) v = 0;
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,12 +299,10 @@ struct DotsArgs {
     int n_bins_pad;
     const float2* ell_val;
     const uint16_t* ell_col;
-    const uint16_t* row_len;
+    const uint16_t* row_len;   // per permuted row slot (wave-uniform, multiple of 4)
+    const uint16_t* row_bin;   // permuted row slot -> output bin (rows sorted by length so a wave's rows are alike)
     float* out_db;     // [n_frames][n_bins]
     float2* out_cplx;  // optional
-    int do_peaks;
-    size_t frame0;     // global index of this launch's first frame (for the peak outputs)
-    PeakParamsDev pk;
 };
 
 #define PVQ_REF_POWER (0.3f * 0.3f)
@@ -261,9 +313,6 @@ __global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* Xs = reinterpret_cast<float2*>(smem_raw);             // [DT_FB][xc]
     float* red = reinterpret_cast<float*>(Xs + DT_FB * a.xc);     // [2][DT_FB][4]
-    const int npad = (a.n_bins + 63) / 64 * 64;
-    float* dbs = red + 2 * DT_FB * 4;                             // [DT_FB][npad] final dB values (fused peaks)
-    unsigned char* pk_scratch = reinterpret_cast<unsigned char*>(dbs + DT_FB * npad);
     const int tid = threadIdx.x;
     const int f0 = blockIdx.x * DT_FB;
     for (int idx = tid; idx < DT_FB * a.xc; idx += 256) {
@@ -281,30 +330,43 @@ __global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
         mx[fb] = -3.40282347e+38f;
         mn[fb] = 3.40282347e+38f;
     }
+    int kbin[PER];
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int k = tid + t * 256;
+        const int k = tid + t * 256;   // permuted row slot
+        kbin[t] = (k < a.n_bins) ? (int)a.row_bin[k] : 0;
         if (k < a.n_bins) {
             float2 acc[DT_FB];
 #pragma unroll
             for (int fb = 0; fb < DT_FB; ++fb) acc[fb] = make_float2(0.0f, 0.0f);
+            // row_len is the longest row of this 64-bin group rounded up to 4 (shorter rows are padded
+            // with zero coefficients): the trip count is wave-uniform and the 4 entry loads of a step
+            // are independent, so the L2 latency of the kernel stream is paid once per 4 entries
             const int len = a.row_len[k];
-            for (int e = 0; e < len; ++e) {
-                const float2 v = a.ell_val[(size_t)e * a.n_bins_pad + k];
-                const uint32_t cc = a.ell_col[(size_t)e * a.n_bins_pad + k];
-                const int col = cc & 0x7fffu;
-                const float sg = (cc & 0x8000u) ? -1.0f : 1.0f;
+            for (int e = 0; e < len; e += 4) {
+                float2 v[4];
+                uint32_t cc[4];
 #pragma unroll
-                for (int fb = 0; fb < DT_FB; ++fb) {
-                    float2 x = Xs[fb * a.xc + col];
-                    x.y *= sg;
-                    acc[fb].x += v.x * x.x - v.y * x.y;
-                    acc[fb].y += v.x * x.y + v.y * x.x;
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = a.ell_val[(size_t)(e + u) * a.n_bins_pad + k];
+                    cc[u] = a.ell_col[(size_t)(e + u) * a.n_bins_pad + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = cc[u] & 0x7fffu;
+                    const float sg = (cc[u] & 0x8000u) ? -1.0f : 1.0f;   // conj(X) entries (vqt.rs:896-910)
+                    const float vxs = v[u].x * sg, vys = v[u].y * sg;
+#pragma unroll
+                    for (int fb = 0; fb < DT_FB; ++fb) {
+                        const float2 x = Xs[fb * a.xc + col];
+                        acc[fb].x += v[u].x * x.x - vys * x.y;
+                        acc[fb].y += vxs * x.y + v[u].y * x.x;
+                    }
                 }
             }
 #pragma unroll
             for (int fb = 0; fb < DT_FB; ++fb) {
-                if (a.out_cplx && f0 + fb < a.n_frames) a.out_cplx[(size_t)(f0 + fb) * a.n_bins + k] = acc[fb];
+                if (a.out_cplx && f0 + fb < a.n_frames) a.out_cplx[(size_t)(f0 + fb) * a.n_bins + kbin[t]] = acc[fb];
                 const float ns = acc[fb].x * acc[fb].x + acc[fb].y * acc[fb].y;
                 const float v = 10.0f * log10f(fmaxf(ns, PVQ_A_MIN)) - ref_db;
                 d[t][fb] = v;
@@ -343,18 +405,10 @@ __global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
                 if (k < a.n_bins) {
                     const float c = fmaxf(d[t][fb], floor_db);
                     const float r = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
-                    a.out_db[(size_t)(f0 + fb) * a.n_bins + k] = r;
-                    if (a.do_peaks) dbs[fb * npad + k] = r;
+                    a.out_db[(size_t)(f0 + fb) * a.n_bins + kbin[t]] = r;
                 }
             }
         }
-    }
-    if (a.do_peaks) {
-        __syncthreads();
-        const int wv = tid >> 6;  // DT_FB == 4 waves: one frame each
-        if (f0 + wv < a.n_frames)
-            peaks_wave(dbs + wv * npad, pk_scratch + wv * peaks_scratch_bytes(a.n_bins, a.pk.dist), a.frame0 + f0 + wv,
-                       a.pk, tid & 63);
     }
 }
 
@@ -362,7 +416,7 @@ __global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
 // host side
 // ------------------------------------------------------------------------------------------------
 bool Vqt::blockdft_applicable(size_t hop) const {
-    if (!has_device() || hop < (size_t)GM_BK || (hop & (hop - 1)) != 0 || hop > 4096) return false;
+    if (!has_device() || hop < 32 || (hop & (hop - 1)) != 0 || hop > 4096) return false;
     if (n_bins() > 1024) return false;
     for (const WindowGroup& g : plan_.kernel.window_groups) {
         const size_t ws = g.window_size();
@@ -399,7 +453,8 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         while ((1 << B.levels) < B.nb) ++B.levels;
         B.n_cols = D.n_cols;
         B.tile0 = tile;
-        B.n_tiles = (D.n_cols + CB_C - 1) / CB_C;
+        const int pad_cols = kGemmVariants[gemm_variant_index()].bn / 2;  // complex columns per GEMM tile
+        B.n_tiles = ((D.n_cols + pad_cols - 1) / pad_cols) * (pad_cols / CB_C);
         B.tw_off = tw_off;
         B.s_rel = (long long)groups[g].window_begin - (long long)plan_.params.n_fft;  // + n_lead + hop at launch
         tile += B.n_tiles;
@@ -431,41 +486,55 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
             }
         }
     }
-    // ELL-packed sparse kernel addressed by X column
+    // ELL-packed sparse kernel addressed by X column.  Rows are assigned to lanes in order of
+    // decreasing length so that the 64 rows a wave walks in lock step have similar lengths.
     const int nb = (int)n_bins();
     t->n_bins_pad = (nb + 63) / 64 * 64;
-    std::vector<uint16_t> row_len(t->n_bins_pad, 0);
-    int ell_len = 0;
+    struct RowRef { int bin; int g; uint32_t r; int len; };
+    std::vector<RowRef> rows;
     for (size_t g = 0; g < groups.size(); ++g) {
         const CsrMatrix& A = groups[g].filter_bank;
         const CsrMatrix& Bm = groups[g].negative_filter_bank;
         for (uint32_t r = 0; r < A.rows; ++r) {
             int len = (int)(A.row_ptr[r + 1] - A.row_ptr[r]);
             if (Bm.nnz() > 0) len += (int)(Bm.row_ptr[r + 1] - Bm.row_ptr[r]);
-            row_len[groups[g].first_bin + r] = (uint16_t)len;
-            ell_len = std::max(ell_len, len);
+            rows.push_back(RowRef{(int)(groups[g].first_bin + r), (int)g, r, len});
         }
+    }
+    std::stable_sort(rows.begin(), rows.end(), [](const RowRef& x, const RowRef& y) { return x.len > y.len; });
+    std::vector<uint16_t> row_len(t->n_bins_pad, 0), row_bin(t->n_bins_pad, 0);
+    int ell_len = 0;
+    for (size_t i = 0; i < rows.size(); ++i) {
+        row_len[i] = (uint16_t)rows[i].len;
+        row_bin[i] = (uint16_t)rows[i].bin;
+        ell_len = std::max(ell_len, rows[i].len);
+    }
+    ell_len = (ell_len + 3) / 4 * 4;
+    for (int k0 = 0; k0 < t->n_bins_pad; k0 += 64) {  // wave-uniform, multiple of 4
+        uint16_t m = 0;
+        for (int k = k0; k < k0 + 64; ++k) m = std::max(m, row_len[k]);
+        m = (uint16_t)((m + 3) / 4 * 4);
+        for (int k = k0; k < k0 + 64; ++k) row_len[k] = m;
     }
     t->ell_len = ell_len;
     std::vector<float2> ell_val((size_t)std::max(ell_len, 1) * t->n_bins_pad, make_float2(0.0f, 0.0f));
     std::vector<uint16_t> ell_col((size_t)std::max(ell_len, 1) * t->n_bins_pad, 0);
-    for (size_t g = 0; g < groups.size(); ++g) {
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const size_t g = (size_t)rows[i].g;
+        const uint32_t r = rows[i].r;
         const CsrMatrix& A = groups[g].filter_bank;
         const CsrMatrix& Bm = groups[g].negative_filter_bank;
         const int xoff = t->groups[g].tile0 * CB_C;
-        for (uint32_t r = 0; r < A.rows; ++r) {
-            const int k = (int)(groups[g].first_bin + r);
-            int e = 0;
-            for (uint32_t i = A.row_ptr[r]; i < A.row_ptr[r + 1]; ++i, ++e) {
-                ell_val[(size_t)e * t->n_bins_pad + k] = make_float2(A.values[i].re, A.values[i].im);
-                ell_col[(size_t)e * t->n_bins_pad + k] = (uint16_t)(xoff + A.col_idx[i]);
-            }
-            if (Bm.nnz() > 0)
-                for (uint32_t i = Bm.row_ptr[r]; i < Bm.row_ptr[r + 1]; ++i, ++e) {
-                    ell_val[(size_t)e * t->n_bins_pad + k] = make_float2(Bm.values[i].re, -Bm.values[i].im);
-                    ell_col[(size_t)e * t->n_bins_pad + k] = (uint16_t)((xoff + Bm.col_idx[i]) | 0x8000u);
-                }
+        int e = 0;
+        for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q, ++e) {
+            ell_val[(size_t)e * t->n_bins_pad + i] = make_float2(A.values[q].re, A.values[q].im);
+            ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)(xoff + A.col_idx[q]);
         }
+        if (Bm.nnz() > 0)
+            for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q, ++e) {
+                ell_val[(size_t)e * t->n_bins_pad + i] = make_float2(Bm.values[q].re, -Bm.values[q].im);
+                ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)((xoff + Bm.col_idx[q]) | 0x8000u);
+            }
     }
     if (tile * CB_C >= 0x8000) {
         free_blockdft_tables(t);
@@ -477,7 +546,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_ell_val, ell_val) && up(&t->d_ell_col, ell_col) &&
-              up(&t->d_row_len, row_len);
+              up(&t->d_row_len, row_len) && up(&t->d_row_bin, row_bin);
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -493,7 +562,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     if (st != PVQ_OK) return st;
     BlockDftTables* t = dev_->block;
     const int ntot = t->n_tiles * GM_BN, xc = t->n_tiles * CB_C;
-    const size_t chunk = std::min(n_frames, kChunkFrames);
+    const size_t chunk = std::min(n_frames, chunk_frames());
     const size_t rows_cap = chunk + t->nb_max - 1;
     const size_t p_bytes = rows_cap * ntot * sizeof(float), x_bytes = chunk * xc * sizeof(float2);
     if (t->p_cap < p_bytes) {
@@ -515,18 +584,26 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         const size_t fbeg = c * chunk;
         const size_t nf = std::min(chunk, n_frames - fbeg);
         const int n_rows = (int)(nf + t->nb_max - 1);
+        const GemmVariant& gv = kGemmVariants[gemm_variant_index()];
         GemmArgs ga;
-        ga.pcm = d_pcm;
-        ga.n_samples = n_samples;
+        // rebase the stream so that every byte offset of this launch fits 32 bits
+        const long long first_needed = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop -
+                                       (long long)plan_.params.n_fft;
+        const long long rebase = std::max<long long>(0, std::min<long long>(first_needed, n_samples));
+        const long long extent = std::min<long long>(n_samples - rebase, (long long)(nf + 2) * (long long)hop +
+                                                                            (long long)plan_.params.n_fft + 4096);
+        ga.pcm_base = d_pcm + rebase;
+        ga.pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
         ga.E = t->d_E;
         ga.ld = ntot;
         ga.P = t->d_P;
         ga.n_rows = n_rows;
         ga.K = (int)hop;
         ga.tile_s = t->d_tile_s;
-        ga.base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop;
+        ga.base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
         slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-        hipLaunchKernelGGL(blockdft_gemm, dim3(t->n_tiles, (n_rows + GM_BM - 1) / GM_BM), dim3(256), 0, stream, ga);
+        hipLaunchKernelGGL(gv.kernel, dim3(t->n_tiles * GM_BN / gv.bn, (n_rows + gv.bm - 1) / gv.bm), dim3(gv.threads), 0,
+                           stream, ga);
         slot_end(SLOT_BLOCKDFT_GEMM, stream);
         CombineArgs ca;
         ca.P = t->d_P;
@@ -550,29 +627,20 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.ell_val = t->d_ell_val;
         da.ell_col = t->d_ell_col;
         da.row_len = t->d_row_len;
+        da.row_bin = t->d_row_bin;
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
-        da.do_peaks = 0;  // peaks run as their own launch below: the latency-bound peak logic wants the
-                          // high occupancy this LDS-heavy kernel cannot give it (measured: fused +77 us, separate +29 us per 8192 frames)
-        da.frame0 = fbeg;
-        if (pk) da.pk = *pk; else std::memset(&da.pk, 0, sizeof da.pk);
-        const size_t lds = sizeof(float2) * DT_FB * xc + sizeof(float) * 2 * DT_FB * 4 +
-                           sizeof(float) * DT_FB * ((nb + 63) / 64 * 64) +
-                           0;
+        const size_t lds = sizeof(float2) * DT_FB * xc + sizeof(float) * 2 * DT_FB * 4;
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
         hipLaunchKernelGGL(blockdft_dots_db, dim3((unsigned)((nf + DT_FB - 1) / DT_FB)), dim3(256), lds, stream, da);
         slot_end(SLOT_BLOCKDFT_DOTS, stream);
-        if (pk) {
-            PeakParamsDev p2 = *pk;  // outputs of this chunk
-            const size_t words = (nb + 31) / 32;
-            if (p2.mask) p2.mask += fbeg * words;
-            if (p2.count) p2.count += fbeg;
-            if (p2.center) p2.center += fbeg * p2.max_peaks;
-            if (p2.size) p2.size += fbeg * p2.max_peaks;
-            slot_begin(SLOT_PEAKS, stream);
-            launch_peaks_kernel(d_out_db + fbeg * nb, nf, p2, stream);
-            slot_end(SLOT_PEAKS, stream);
-        }
+    }
+    if (pk) {
+        // one launch over the whole batch: the wave-per-frame peak logic is latency-bound and wants as
+        // many frames in flight as possible (measured: 8 x 55 us per 8192-frame launch vs 236 us at once)
+        slot_begin(SLOT_PEAKS, stream);
+        launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
+        slot_end(SLOT_PEAKS, stream);
     }
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_BLOCKDFT;

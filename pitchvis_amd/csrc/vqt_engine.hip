@@ -261,8 +261,6 @@ struct FftArgs {
     const uint16_t* ent_col;
     float* out_db;
     float2* out_cplx;
-    int do_peaks;
-    PeakParamsDev pk;
 };
 
 template <int BLOCK, int E>
@@ -272,8 +270,6 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
     float2* spec = Z + lpad(a.n_tw) + 1;
     float2* xv = spec + a.max_cols;
     float* red = reinterpret_cast<float*>(xv + a.n_bins);
-    float* dbs = red + 32;                                      // frame dB values for the fused peaks
-    unsigned char* pk_scratch = reinterpret_cast<unsigned char*>(dbs + ((a.n_bins + 63) / 64 * 64));
     const int tid = threadIdx.x;
 
     for (int frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
@@ -337,12 +333,8 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
         if (a.out_cplx) {
             for (int k = tid; k < a.n_bins; k += BLOCK) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
         }
-        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, a.do_peaks ? dbs : nullptr, tid);
+        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, nullptr, tid);
         __syncthreads();
-        if (a.do_peaks) {
-            if (tid < 64) peaks_wave(dbs, pk_scratch, (size_t)frame, a.pk, tid);
-            __syncthreads();
-        }
     }
 }
 
@@ -352,7 +344,8 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int PK_WAVES = 4;
 
-__global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames(const float* __restrict__ db, int n_frames, PeakParamsDev a) {
+template <int NK>
+__global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames(const float* __restrict__ db, int n_frames, PeakParamsDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = a.n_bins;
@@ -365,7 +358,7 @@ __global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames(const float* __res
         for (int i = lane; i < n; i += 64) x[i] = src[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        peaks_wave(x, scratch, (size_t)frame, a, lane);
+        peaks_wave_nk<NK>(x, scratch, (size_t)frame, a, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -530,8 +523,6 @@ uint32_t Vqt::last_kernel_launches(uint32_t* out, uint32_t cap) const {
 pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                 float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     FftArgs a;
-    a.do_peaks = pk ? 1 : 0;
-    if (pk) a.pk = *pk; else std::memset(&a.pk, 0, sizeof a.pk);
     a.pcm = d_pcm;
     a.n_lead = (long long)n_lead;
     a.hop = (long long)hop;
@@ -552,8 +543,7 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     a.out_cplx = reinterpret_cast<float2*>(d_out_cplx);
 
     const size_t lds = sizeof(float2) * ((size_t)(dev_->n_tw + (dev_->n_tw >> 4)) + 1 + dev_->max_cols + a.n_bins) +
-                       sizeof(float) * 32 + sizeof(float) * ((a.n_bins + 63) / 64 * 64) +
-                       (pk ? peaks_scratch_bytes(a.n_bins, pk->dist) : 0);
+                       sizeof(float) * 32;
     const int grid = (int)std::min<size_t>(n_frames, 1u << 20);
     slot_begin(SLOT_FFT_FRAMES, stream);
     if (dev_->n_tw <= 512 * 16) {
@@ -566,6 +556,11 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
         hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, a);
     }
     slot_end(SLOT_FFT_FRAMES, stream);
+    if (pk) {  // peak / note detection as its own launch (one wavefront per frame)
+        slot_begin(SLOT_PEAKS, stream);
+        launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
+        slot_end(SLOT_PEAKS, stream);
+    }
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_FFT;
     last_frames_per_launch_ = (uint32_t)n_frames;
@@ -660,7 +655,10 @@ void Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakPara
     const int npad = (a.n_bins + 63) / 64 * 64;
     const size_t lds = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
     const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
-    hipLaunchKernelGGL(peaks_frames, dim3(grid), dim3(PK_WAVES * 64), lds, stream, d_db, (int)n_frames, a);
+    if (a.n_bins <= 256)
+        hipLaunchKernelGGL(peaks_frames<4>, dim3(grid), dim3(PK_WAVES * 64), lds, stream, d_db, (int)n_frames, a);
+    else
+        hipLaunchKernelGGL(peaks_frames<16>, dim3(grid), dim3(PK_WAVES * 64), lds, stream, d_db, (int)n_frames, a);
 }
 
 pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const AnalysisParameters& ap,
