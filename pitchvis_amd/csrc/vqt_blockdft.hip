@@ -39,8 +39,7 @@ namespace pvq {
 constexpr int GM_BN = 64;   // granularity of the column tiling: 64 floats = 32 complex spectrum columns
 constexpr int CB_T = 64;    // frames per combine workgroup
 constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
-constexpr int CB_MAX_NB = 64;
-constexpr int CB_MAX_R = CB_T + CB_MAX_NB - 1;  // rows of P a combine workgroup stages
+constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
 constexpr int DT_FB = 4;    // frames per dots workgroup
 static size_t chunk_frames() {  // frames per sub-batch: P and X of one chunk should stay in the Infinity Cache
     const char* e = getenv("PVQ_CHUNK_FRAMES");  // developer knob
@@ -239,34 +238,37 @@ struct CombineArgs {
     const float2* comb_tw;
 };
 
+// CT frames x CW complex columns per workgroup; windows of up to MAXNB hop blocks.
+template <int CT, int CW, int MAXNB>
 __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
-    __shared__ float2 A[CB_MAX_R][CB_C];
+    constexpr int MAXR = CT + MAXNB - 1;
+    __shared__ float2 A[MAXR][CW];
     const int tid = threadIdx.x;
-    const int ct = blockIdx.x;
-    const int f0 = blockIdx.y * CB_T;
-    const BlockGroup G = a.groups[a.tile_group[ct]];
-    const int R = CB_T + G.nb - 1;
-    const int c = tid & (CB_C - 1);
+    const int col0 = blockIdx.x * CW;          // first complex column of this tile (global X column)
+    const int f0 = blockIdx.y * CT;
+    const BlockGroup G = a.groups[a.tile_group[col0 / CB_C]];
+    const int R = CT + G.nb - 1;
+    const int c = tid & (CW - 1);
     // stage rows f0 .. f0+R-1 of this column tile
-    for (int idx = tid; idx < R * CB_C; idx += 256) {
-        const int j = idx / CB_C;
+    for (int idx = tid; idx < R * CW; idx += 256) {
+        const int j = idx / CW;
         const int row = f0 + j;
         float2 v = make_float2(0.0f, 0.0f);
-        if (row < a.n_rows) v = *reinterpret_cast<const float2*>(a.P + (size_t)row * a.ld + ct * GM_BN + 2 * c);
+        if (row < a.n_rows) v = *reinterpret_cast<const float2*>(a.P + (size_t)row * a.ld + 2 * (col0 + c));
         A[j][c] = v;
     }
     __syncthreads();
-    constexpr int PER = (CB_MAX_R * CB_C + 255) / 256;
+    constexpr int PER = (MAXR * CW + 255) / 256;
     int valid = R;
     for (int l = 0; l < G.levels; ++l) {
         const int s = 1 << l;
         valid -= s;  // rows with a complete span after this level
-        const float2 w = a.comb_tw[G.tw_off + l * (G.n_tiles * CB_C) + (ct - G.tile0) * CB_C + c];
+        const float2 w = a.comb_tw[G.tw_off + l * (G.n_tiles * CB_C) + (col0 - G.tile0 * CB_C) + c];
         float2 v[PER];
 #pragma unroll
         for (int t = 0; t < PER; ++t) {
             const int idx = tid + t * 256;
-            const int j = idx / CB_C;
+            const int j = idx / CW;
             if (j < valid) {
                 const float2 lo = A[j][c], hi = A[j + s][c];
                 v[t] = make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
@@ -276,15 +278,15 @@ __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
 #pragma unroll
         for (int t = 0; t < PER; ++t) {
             const int idx = tid + t * 256;
-            const int j = idx / CB_C;
+            const int j = idx / CW;
             if (j < valid) A[j][c] = v[t];
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < CB_T * CB_C; idx += 256) {
-        const int j = idx / CB_C;
+    for (int idx = tid; idx < CT * CW; idx += 256) {
+        const int j = idx / CW;
         const int f = f0 + j;
-        if (f < a.n_frames) a.X[(size_t)f * a.xc + ct * CB_C + c] = A[j][c];
+        if (f < a.n_frames) a.X[(size_t)f * a.xc + col0 + c] = A[j][c];
     }
 }
 
@@ -616,7 +618,12 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         ca.groups = t->d_groups;
         ca.comb_tw = t->d_comb_tw;
         slot_begin(SLOT_BLOCKDFT_COMBINE, stream);
-        hipLaunchKernelGGL(blockdft_combine, dim3(t->n_tiles, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256), 0, stream, ca);
+        if (t->nb_max <= 64)
+            hipLaunchKernelGGL((blockdft_combine<CB_T, 32, 64>), dim3(t->n_tiles, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256), 0,
+                               stream, ca);
+        else
+            hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 256>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256),
+                               0, stream, ca);
         slot_end(SLOT_BLOCKDFT_COMBINE, stream);
         DotsArgs da;
         da.X = t->d_X;

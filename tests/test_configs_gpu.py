@@ -1,0 +1,109 @@
+"""BASELINE.json configs 3-5 as parity-test cases (config 2 is the bench line, config 1 is
+tests/test_parity_gpu.py::test_sweep_parity)."""
+import numpy as np
+import pytest
+
+import oracle as O
+import pitchvis_amd as P
+from pitchvis_amd.sharding import plan_shard
+from helpers import get_geom, white_noise, mask_to_indices
+from synth import piano_roll, active_notes
+from test_parity_gpu import assert_parity, input_peak
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _run(v, pcm, hop, nf, n_lead=0):
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm, np.float32)).cuda()
+    d_db = torch.empty((nf, v.n_bins), device="cuda")
+    words = (v.n_bins + 31) // 32
+    d_mask = torch.zeros((nf, words), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    d_c = torch.zeros((nf, 64), device="cuda")
+    d_s = torch.zeros((nf, 64), device="cuda")
+    v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt, d_c, d_s, 64, n_lead=n_lead)
+    torch.cuda.synchronize()
+    return (d_db.cpu().numpy(), d_mask.cpu().numpy().view(np.uint32), d_cnt.cpu().numpy(), d_c.cpu().numpy(),
+            d_s.cpu().numpy())
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config3_sharded_equals_unsharded(world):
+    """config 3 geometry (48 kHz, 8 oct x 36 = 288 bins, hop 256): frame shards with their window-union
+    halo reproduce the unsharded batch bit for bit (no collective on the data path)."""
+    pp, op = get_geom("bench_48k_288")
+    v = P.Vqt.new(pp, 0)
+    hop, nf = 256, 8192
+    pcm = white_noise(hop * nf, 0x5EED0003)
+    full = _run(v, pcm, hop, nf)
+    assert v.last_algo() == P.ALGO_BLOCKDFT
+    for r in range(world):
+        s = plan_shard(nf, hop, v.window_union, r, world)
+        part = _run(v, pcm[s.sample_begin:s.sample_end], hop, s.n_frames, n_lead=s.n_lead)
+        sl = slice(s.first_frame, s.first_frame + s.n_frames)
+        assert np.array_equal(part[0], full[0][sl]) and np.array_equal(part[1], full[1][sl])
+        assert np.array_equal(part[2], full[2][sl])
+    # spot parity of the unsharded result
+    ov = O.OracleVqt(op)
+    for f in (0, 63, 4095, nf - 1):
+        end = (f + 1) * hop
+        x = np.zeros(op.n_fft, np.float32)
+        beg = max(end - op.n_fft, 0)
+        x[op.n_fft - (end - beg):] = pcm[beg:end]
+        assert np.abs(full[0][f] - ov.calculate_vqt_instant_in_db(x)).max() <= 1e-2
+
+
+@pytest.mark.parametrize("name", ["hires_96k_360", "hires_96k_840"])
+def test_config4_96k_stereo_hop128(name):
+    """config 4: 96 kHz, hop 128, 10 octaves from 27.5 Hz (55 Hz would exceed Nyquist);
+    the reference is mono end to end, so the two channels are two independent streams."""
+    pp, op = get_geom(name)
+    with pytest.raises(P.AboveNyquist):
+        P.Vqt.new(P.VqtParameters(sr=96000.0, range=P.VqtRange(55.0, 10, pp.range.buckets_per_octave)), None)
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    hop, nf, n_lead = 128, 192, 40000
+    for seed in (0x5EED0004, 0x5EED0005):  # left, right
+        pcm = white_noise(n_lead + hop * nf, seed)
+        d_pcm = torch.from_numpy(pcm).cuda()
+        d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
+        v.calculate_batch_db_device(d_pcm, hop, nf, d_db, n_lead=n_lead, d_out_cplx=d_cx); torch.cuda.synchronize()
+        assert v.last_algo() == P.ALGO_BLOCKDFT  # 256 hop blocks per 32768-sample window
+        wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
+        assert_parity(d_db.cpu().numpy(), d_cx.cpu().numpy().view(np.complex64)[..., 0], wdb, wcx,
+                      xpeak=input_peak(pcm, hop, nf, n_lead, v.window_union), sr=op.sr)
+
+
+def test_config5_polyphonic_notes():
+    """config 5 with a synthetic additive piano roll (no SoundFont / MIDI assets exist here): the note
+    lists of the GPU path equal the CPU oracle's, and both recover the ground truth."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    pcm, notes = piano_roll(op.sr, 12.0, 5)
+    hop = 2048
+    nf = len(pcm) // hop
+    db, mask, cnt, ctr, sz = _run(v, pcm, hop, nf)
+    wdb = ov.calculate_batch(pcm, hop, nf)
+    tp = fp = fn = explained = ndet = 0
+    mismatched = 0
+    for f in range(nf):
+        t = (f + 1) * hop / op.sr - v.delay
+        truth = set(active_notes(notes, t))
+        k = int(cnt[f])
+        det = set(int(round(c * 12 / 36)) + 33 for c, s in zip(ctr[f, :k], sz[f, :k]) if s > 12.0)  # A1 = MIDI 33 (train.rs:34)
+        _, wce, wsz = O.analyze_frame(wdb[f], op.min_freq, op.octaves, op.buckets_per_octave)
+        wdet = set(int(round(c * 12 / 36)) + 33 for c, s in zip(wce, wsz) if s > 12.0)
+        mismatched += det != wdet
+        if not truth:
+            continue
+        tp += len(det & truth); fp += len(det - truth); fn += len(truth - det)
+        partials = set(int(round(m + 12 * np.log2(h))) for m in truth for h in range(1, 7))
+        explained += len(det & partials); ndet += len(det)
+    recall, precision, spectral_precision = tp / (tp + fn), tp / (tp + fp), explained / ndet
+    print(f"config5: note recall {recall:.3f}, note precision {precision:.3f} (overtones count as false), "
+          f"peaks explained by a partial of an active note {spectral_precision:.3f}; "
+          f"frames whose GPU note list differs from the oracle's: {mismatched}/{nf}")
+    assert mismatched <= nf // 50          # only threshold-straddling peaks (size within tolerance of 12 dB) may differ
+    assert recall >= 0.9 and spectral_precision >= 0.9
