@@ -40,7 +40,6 @@ constexpr int GM_BN = 64;   // granularity of the column tiling: 64 floats = 32 
 constexpr int CB_T = 64;    // frames per combine workgroup
 constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
-constexpr int DT_FB = 4;    // frames per dots workgroup
 static size_t chunk_frames() {  // frames per sub-batch: P and X of one chunk should stay in the Infinity Cache
     const char* e = getenv("PVQ_CHUNK_FRAMES");  // developer knob
     const long v = e ? atol(e) : 16384;
@@ -109,6 +108,8 @@ struct GemmArgs {
     int K;                    // hop
     const long long* tile_s;  // per 64-float column tile: window begin relative to the n_fft buffer end (w0 - n_fft)
     long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
+    int n_col_tiles;          // column tiles of this kernel's BN
+    int p_rows;               // row capacity of the tile-major P: P[(tile64 * p_rows + row) * 64 + (col & 63)]
 };
 
 // BM x BN output tile, BK k-step, WM x WN waves, each wave (BM/WM) x (BN/WN) as TM x TN 32x32 MFMA tiles.
@@ -120,13 +121,21 @@ __global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_PER = BM * BK / NT;            // dwords of A per thread per k-step
     constexpr int A_ROWS_PER_PASS = NT / BK;
-    constexpr int B_PER = BK * BN / 4 / NT;        // float4 of B per thread per k-step
-    constexpr int B_ROWS_PER_PASS = NT * 4 / BN;
-    static_assert(A_PER >= 1 && B_PER >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
+    constexpr int BV = (BK * BN / NT >= 4) ? 4 : (BK * BN / NT);   // floats per B vector load (4, 2 or 1)
+    constexpr int B_PER = BK * BN / BV / NT;       // vector loads of B per thread per k-step
+    constexpr int B_ROWS_PER_PASS = NT * BV / BN;
+    static_assert(A_PER >= 1 && B_PER >= 1 && BV >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
+    typedef float bvec_t __attribute__((ext_vector_type(BV)));
     __shared__ float As[2][BM][BK + 1];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x, mt = blockIdx.y;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
+    // so give every XCD whole row panels: all column tiles that re-read one A panel hit one L2.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, bi = b >> 3;
+    const int nt = bi % a.n_col_tiles;
+    const int mt = (bi / a.n_col_tiles) * 8 + xcd;
+    if (mt * BM >= a.n_rows) return;
     const int j0 = mt * BM;
     const int wm = wave / WN, wn = wave % WN;
     // every 64-float tile inside this BN-wide tile belongs to the same group (groups are padded to BN)
@@ -134,9 +143,9 @@ __global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
 
     float ra[A_PER];
-    float4 rb[B_PER];
+    bvec_t rb[B_PER];
     const int a_row = tid / BK, a_col = tid % BK;
-    const int b_row = (tid * 4) / BN, b_col = (tid * 4) % BN;
+    const int b_row = (tid * BV) / BN, b_col = (tid * BV) % BN;
     // byte offset of A[j0 + a_row][a_col]; negative indices wrap to huge unsigned offsets -> out of range -> 0
     const unsigned a_off0 = (unsigned)((s + (long long)(j0 + a_row) * a.K + a_col) * 4ll);
     const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
@@ -155,13 +164,13 @@ __global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
         _Pragma("unroll") for (int i = 0; i < A_PER; ++i) ra[i] = __builtin_bit_cast(                          \
             float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
         _Pragma("unroll") for (int i = 0; i < B_PER; ++i) rb[i] =                                              \
-            *reinterpret_cast<const float4*>(e_ptr + (size_t)((k0) + i * B_ROWS_PER_PASS) * a.ld);             \
+            *reinterpret_cast<const bvec_t*>(e_ptr + (size_t)((k0) + i * B_ROWS_PER_PASS) * a.ld);             \
     }
 #define PVQ_GEMM_STORE(buf)                                                                                    \
     {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < A_PER; ++i) As[buf][a_row + i * A_ROWS_PER_PASS][a_col] = ra[i]; \
         _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                                      \
-            *reinterpret_cast<float4*>(&Bs[buf][b_row + i * B_ROWS_PER_PASS][b_col]) = rb[i];                  \
+            *reinterpret_cast<bvec_t*>(&Bs[buf][b_row + i * B_ROWS_PER_PASS][b_col]) = rb[i];                  \
     }
 
     const int n_iter = a.K / BK;
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = j0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a.n_rows) a.P[(size_t)row * a.ld + col] = acc[i][j][r];
+                if (row < a.n_rows) a.P[((size_t)(col >> 6) * a.p_rows + row) * 64 + (col & 63)] = acc[i][j][r];
             }
         }
 }
@@ -215,6 +224,10 @@ static const GemmVariant kGemmVariants[] = {
     {256, 64, blockdft_gemm<256, 64, 16, 4, 1>, 256},
     {128, 128, blockdft_gemm<128, 128, 16, 2, 2>, 256},
     {256, 128, blockdft_gemm<256, 128, 16, 4, 2>, 512},
+    {128, 64, blockdft_gemm<128, 64, 8, 2, 2>, 256},
+    {256, 64, blockdft_gemm<256, 64, 8, 4, 1>, 256},
+    {256, 64, blockdft_gemm<256, 64, 16, 4, 2>, 512},
+    {64, 64, blockdft_gemm<64, 64, 16, 1, 2>, 128},
 };
 static int gemm_variant_index() {
     const char* e = getenv("PVQ_GEMM_VARIANT");  // developer knob; the default is the measured best
@@ -228,7 +241,7 @@ static int gemm_variant_index() {
 // ------------------------------------------------------------------------------------------------
 struct CombineArgs {
     const float* P;
-    int ld;            // Ntot floats
+    int p_rows;        // row capacity of the tile-major P
     float2* X;         // [n_frames][xc]
     int xc;
     int n_frames;      // frames in this chunk
@@ -254,7 +267,8 @@ __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
         const int j = idx / CW;
         const int row = f0 + j;
         float2 v = make_float2(0.0f, 0.0f);
-        if (row < a.n_rows) v = *reinterpret_cast<const float2*>(a.P + (size_t)row * a.ld + 2 * (col0 + c));
+        if (row < a.n_rows)
+            v = *reinterpret_cast<const float2*>(a.P + ((size_t)(col0 / CB_C) * a.p_rows + row) * 64 + 2 * ((col0 % CB_C) + c));
         A[j][c] = v;
     }
     __syncthreads();
@@ -311,6 +325,7 @@ struct DotsArgs {
 #define PVQ_A_MIN (1e-6f * 1e-6f)
 #define PVQ_TOP_DB 60.0f
 
+template <int DT_FB>
 __global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* Xs = reinterpret_cast<float2*>(smem_raw);             // [DT_FB][xc]
@@ -447,16 +462,30 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     t->n_groups = (int)groups.size();
     const double pi = 3.14159265358979323846;
     int tile = 0, tw_off = 0;
+    // Only the spectrum columns some kernel row actually reads are computed (e.g. 602 of 871 at
+    // 48 kHz / 7x36): col_of[g][i] is the i-th used column of group g, idx_of[g][c] its compressed index.
+    std::vector<std::vector<uint32_t>> col_of(groups.size());
+    std::vector<std::vector<int>> idx_of(groups.size());
     for (size_t g = 0; g < groups.size(); ++g) {
-        const GroupDev& D = dev_->h_groups[g];
+        std::vector<char> used(groups[g].filter_bank.cols + 1, 0);
+        for (uint32_t c : groups[g].filter_bank.col_idx) used[c] = 1;
+        for (uint32_t c : groups[g].negative_filter_bank.col_idx) used[c] = 1;
+        idx_of[g].assign(used.size(), -1);
+        for (uint32_t c = 0; c < used.size(); ++c)
+            if (used[c]) {
+                idx_of[g][c] = (int)col_of[g].size();
+                col_of[g].push_back(c);
+            }
+    }
+    for (size_t g = 0; g < groups.size(); ++g) {
         BlockGroup B{};
         B.nb = (int)(groups[g].window_size() / hop);
         B.levels = 0;
         while ((1 << B.levels) < B.nb) ++B.levels;
-        B.n_cols = D.n_cols;
+        B.n_cols = (int)col_of[g].size();
         B.tile0 = tile;
         const int pad_cols = kGemmVariants[gemm_variant_index()].bn / 2;  // complex columns per GEMM tile
-        B.n_tiles = ((D.n_cols + pad_cols - 1) / pad_cols) * (pad_cols / CB_C);
+        B.n_tiles = ((B.n_cols + pad_cols - 1) / pad_cols) * (pad_cols / CB_C);
         B.tw_off = tw_off;
         B.s_rel = (long long)groups[g].window_begin - (long long)plan_.params.n_fft;  // + n_lead + hop at launch
         tile += B.n_tiles;
@@ -473,18 +502,19 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         const BlockGroup& B = t->groups[g];
         const double W = (double)groups[g].window_size();
         for (int tt = 0; tt < B.n_tiles; ++tt) tile_group[B.tile0 + tt] = (int)g;
-        for (int c = 0; c < B.n_cols; ++c) {
+        for (int ci = 0; ci < B.n_cols; ++ci) {
+            const long long c = (long long)col_of[g][ci];  // actual spectrum column
             for (size_t m = 0; m < hop; ++m) {
                 // reduce the angle exactly: (c*m) mod W in integers
-                const long long prod = ((long long)c * (long long)m) % (long long)W;
+                const long long prod = (c * (long long)m) % (long long)W;
                 const double ang = -2.0 * pi * (double)prod / W;
-                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * c] = (float)std::cos(ang);
-                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * c + 1] = (float)std::sin(ang);
+                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci] = (float)std::cos(ang);
+                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci + 1] = (float)std::sin(ang);
             }
             for (int l = 0; l < B.levels; ++l) {
-                const long long prod = ((long long)c * (1ll << l)) % (long long)B.nb;
+                const long long prod = (c * (1ll << l)) % (long long)B.nb;
                 const double ang = -2.0 * pi * (double)prod / (double)B.nb;
-                comb_tw[B.tw_off + l * (B.n_tiles * CB_C) + c] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+                comb_tw[B.tw_off + l * (B.n_tiles * CB_C) + ci] = make_float2((float)std::cos(ang), (float)std::sin(ang));
             }
         }
     }
@@ -530,12 +560,12 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         int e = 0;
         for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q, ++e) {
             ell_val[(size_t)e * t->n_bins_pad + i] = make_float2(A.values[q].re, A.values[q].im);
-            ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)(xoff + A.col_idx[q]);
+            ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)(xoff + idx_of[g][A.col_idx[q]]);
         }
         if (Bm.nnz() > 0)
             for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q, ++e) {
                 ell_val[(size_t)e * t->n_bins_pad + i] = make_float2(Bm.values[q].re, -Bm.values[q].im);
-                ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)((xoff + Bm.col_idx[q]) | 0x8000u);
+                ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)((xoff + idx_of[g][Bm.col_idx[q]]) | 0x8000u);
             }
     }
     if (tile * CB_C >= 0x8000) {
@@ -604,12 +634,14 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         ga.tile_s = t->d_tile_s;
         ga.base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
         slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-        hipLaunchKernelGGL(gv.kernel, dim3(t->n_tiles * GM_BN / gv.bn, (n_rows + gv.bm - 1) / gv.bm), dim3(gv.threads), 0,
-                           stream, ga);
+        ga.n_col_tiles = t->n_tiles * GM_BN / gv.bn;
+        ga.p_rows = (int)rows_cap;
+        const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
+        hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, stream, ga);
         slot_end(SLOT_BLOCKDFT_GEMM, stream);
         CombineArgs ca;
         ca.P = t->d_P;
-        ca.ld = ntot;
+        ca.p_rows = (int)rows_cap;
         ca.X = t->d_X;
         ca.xc = xc;
         ca.n_frames = (int)nf;
@@ -618,7 +650,23 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         ca.groups = t->d_groups;
         ca.comb_tw = t->d_comb_tw;
         slot_begin(SLOT_BLOCKDFT_COMBINE, stream);
-        if (t->nb_max <= 64)
+        static const int cvar = getenv("PVQ_COMBINE_VARIANT") ? atoi(getenv("PVQ_COMBINE_VARIANT")) : 2;  // developer knob
+        if (t->nb_max <= 64 && cvar == 1)
+            hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256), 0,
+                               stream, ca);
+        else if (t->nb_max <= 64 && cvar == 2)
+            hipLaunchKernelGGL((blockdft_combine<128, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 127) / 128)), dim3(256), 0,
+                               stream, ca);
+        else if (t->nb_max <= 64 && cvar == 3)
+            hipLaunchKernelGGL((blockdft_combine<128, 8, 64>), dim3(t->n_tiles * 4, (unsigned)((nf + 127) / 128)), dim3(256), 0,
+                               stream, ca);
+        else if (t->nb_max <= 64 && cvar == 4)
+            hipLaunchKernelGGL((blockdft_combine<256, 8, 64>), dim3(t->n_tiles * 4, (unsigned)((nf + 255) / 256)), dim3(256), 0,
+                               stream, ca);
+        else if (t->nb_max <= 64 && cvar == 5)
+            hipLaunchKernelGGL((blockdft_combine<256, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 255) / 256)), dim3(256), 0,
+                               stream, ca);
+        else if (t->nb_max <= 64)
             hipLaunchKernelGGL((blockdft_combine<CB_T, 32, 64>), dim3(t->n_tiles, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256), 0,
                                stream, ca);
         else
@@ -637,9 +685,18 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.row_bin = t->d_row_bin;
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
-        const size_t lds = sizeof(float2) * DT_FB * xc + sizeof(float) * 2 * DT_FB * 4;
+        static const int dfb = getenv("PVQ_DOTS_FB") ? atoi(getenv("PVQ_DOTS_FB")) : 4;  // developer knob
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
-        hipLaunchKernelGGL(blockdft_dots_db, dim3((unsigned)((nf + DT_FB - 1) / DT_FB)), dim3(256), lds, stream, da);
+        if (dfb == 2) {
+            const size_t lds = sizeof(float2) * 2 * xc + sizeof(float) * 2 * 2 * 4;
+            hipLaunchKernelGGL(blockdft_dots_db<2>, dim3((unsigned)((nf + 1) / 2)), dim3(256), lds, stream, da);
+        } else if (dfb == 8) {
+            const size_t lds = sizeof(float2) * 8 * xc + sizeof(float) * 2 * 8 * 4;
+            hipLaunchKernelGGL(blockdft_dots_db<8>, dim3((unsigned)((nf + 7) / 8)), dim3(256), lds, stream, da);
+        } else {
+            const size_t lds = sizeof(float2) * 4 * xc + sizeof(float) * 2 * 4 * 4;
+            hipLaunchKernelGGL(blockdft_dots_db<4>, dim3((unsigned)((nf + 3) / 4)), dim3(256), lds, stream, da);
+        }
         slot_end(SLOT_BLOCKDFT_DOTS, stream);
     }
     if (pk) {
