@@ -90,6 +90,30 @@ __device__ __forceinline__ bool pk_prom_ok_wave(const float (&v)[NK], int n, int
     return ok;
 }
 
+// Windowed, lane-parallel form of the same test: every candidate lane inspects the S samples next to
+// its peak on one side (independent LDS reads, no chain) and records where a higher / a low-enough
+// sample sits; the nearest decisive sample settles the side.  Returns 1 = side passes, 2 = side
+// fails (higher sample or frame edge first), 0 = undecided within S samples (resolved by the
+// wave-cooperative test above, which is exact for any distance).
+template <int S>
+__device__ __forceinline__ int pk_side_window(const float* x, int i, int n, int dir, float h, float P) {
+    unsigned mh = 0u, ml = 0u;
+#pragma unroll
+    for (int s = 1; s <= S; ++s) {
+        const int q = i + dir * s;
+        const bool in = (q >= 0) && (q < n);
+        const float v = x[in ? q : i];
+        const bool hi = !in || v > h;
+        const bool lo = in && (h - v >= P);
+        mh |= (hi ? 1u : 0u) << s;
+        ml |= (lo ? 1u : 0u) << s;
+    }
+    const unsigned any = mh | ml;
+    if (!any) return 0;
+    const unsigned first = any & (0u - any);
+    return (ml & first) ? 1 : 2;
+}
+
 // enhance + promote for one peak (see refine note in vqt_engine.hip)
 __device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
 #pragma clang fp contract(off)
@@ -232,8 +256,22 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
             const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
             pre = xv >= H && (a.dist <= 1 || (bass ? keep0[i] : keep1[i])) && (!(P > 0.0f) || (xv - fmin_ >= P));
         }
-        unsigned long long cm = __ballot(pre);
-        unsigned long long pm = 0;  // peaks of this chunk (wave-uniform)
+        // most candidates are settled by the 16 samples on either side; the rest go to the exact wave test
+        int st = 2;
+        if (pre) {
+            const float P = (i <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
+            if (!(P > 0.0f)) {
+                st = 1;
+            } else {
+                const int l = pk_side_window<16>(x, i, n, -1, xv, P);
+                if (l != 2) {
+                    const int r = pk_side_window<16>(x, i, n, 1, xv, P);
+                    st = (r == 2) ? 2 : ((l == 1 && r == 1) ? 1 : 0);
+                }
+            }
+        }
+        unsigned long long pm = __ballot(st == 1);  // peaks of this chunk (wave-uniform)
+        unsigned long long cm = __ballot(st == 0);
         while (cm) {
             const int b = __builtin_ctzll(cm);
             cm &= cm - 1;
@@ -264,6 +302,104 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
             a.size[frame * a.max_peaks + sidx] = sz;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lean common-case routine (dist <= 1, no plateau peak in the frame).
+// x points at the frame inside an LDS row that carries PK_PAD samples of +INF on both sides, so the
+// walk needs no range checks: running off the frame looks like meeting a higher sample, which is the
+// reference's edge behaviour.  Each side is scanned over a fixed window with a "poisoned running
+// minimum": M = running max; once M exceeds the peak height every later sample counts as +INF;
+// m = min of the surviving samples.  The side passes iff fl(h - m) >= P — exactly the reference test
+// on the minimum of the samples met before the first higher one.  4 VALU + 1 LDS read per step, no
+// masks, two independent chains (left / right).  A lane whose window ends without a decision
+// (no low sample, no higher sample within PK_PAD) is settled by the exact wave-cooperative test.
+// Returns false, having written nothing, when the frame contains a plateau candidate: the caller
+// then runs the generic routine.
+// ------------------------------------------------------------------------------------------------
+constexpr int PK_PAD = 16;
+
+template <int NK>
+__device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
+                                                int lane) {
+    const int n = a.n_bins;
+    const int npad = (n + 63) / 64 * 64;
+    const int words = (n + 31) / 32;
+    const float INF = __builtin_huge_valf();
+    uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);
+    float v[NK];
+    float fmin_ = INF;
+    bool plateau = false;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i = (k << 6) + lane;
+        v[k] = (i < n) ? x[i] : INF;
+        if (i < n) fmin_ = fminf(fmin_, v[k]);
+        // a rise followed by an equal sample may start a plateau peak: leave those frames to the generic code
+        plateau |= (i >= 1 && i < n - 1) && (x[i - 1] < v[k]) && (x[i + 1] == v[k]);
+    }
+    if (__ballot(plateau)) return false;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
+
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if ((k << 6) >= n) break;
+        const int i = (k << 6) + lane;
+        const float xv = v[k];
+        const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
+        const float H = bass ? a.bass_min_height : a.peak_min_height;
+        const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
+        const bool pre = (i >= a.min_bin) && (i < n) && (x[i - 1] < xv) && (x[i + 1] < xv) && (xv >= H) &&
+                         (!(P > 0.0f) || (xv - fmin_ >= P));
+        unsigned long long pm = 0ull;
+        if (__ballot(pre)) {
+            float ML = -INF, mL = INF, MR = -INF, mR = INF;
+#pragma unroll
+            for (int s = 1; s <= PK_PAD; ++s) {
+                const float vl = x[i - s], vr = x[i + s];
+                ML = fmaxf(ML, vl);
+                MR = fmaxf(MR, vr);
+                mL = fminf(mL, (ML > xv) ? INF : vl);
+                mR = fminf(mR, (MR > xv) ? INF : vr);
+            }
+            const bool noP = !(P > 0.0f);
+            const bool okL = noP || (xv - mL >= P), okR = noP || (xv - mR >= P);
+            const bool failed = (!okL && ML > xv) || (!okR && MR > xv);
+            const bool peak = pre && okL && okR;
+            pm = __ballot(peak);
+            unsigned long long cm = __ballot(pre && !peak && !failed);  // window too short: exact test
+            while (cm) {
+                const int b = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                const int ci = (k << 6) + b;
+                const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b));
+                const float Pc = (ci <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
+                if (pk_prom_ok_wave<NK>(v, n, ci, h, Pc, lane)) pm |= 1ull << b;
+            }
+        }
+        if (a.mask) {
+            if (lane == 0 && 2 * k < words) a.mask[frame * words + 2 * k] = (uint32_t)pm;
+            if (lane == 1 && 2 * k + 1 < words) a.mask[frame * words + 2 * k + 1] = (uint32_t)(pm >> 32);
+        }
+        const uint32_t slot = total + __popcll(pm & ((1ull << lane) - 1ull));
+        total += __popcll(pm);
+        if ((pm >> lane) & 1ull) plist[slot] = (uint16_t)i;
+    }
+    if (a.count && lane == 0) a.count[frame] = total;
+    if (a.center) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t lim = total < a.max_peaks ? total : a.max_peaks;
+        for (uint32_t sidx = lane; sidx < lim; sidx += 64) {
+            float ctr, sz;
+            pk_refine(x, (int)plist[sidx], a, ctr, sz);
+            a.center[frame * a.max_peaks + sidx] = ctr;
+            a.size[frame * a.max_peaks + sidx] = sz;
+        }
+    }
+    return true;
 }
 
 }  // namespace pvq

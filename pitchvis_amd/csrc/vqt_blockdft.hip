@@ -42,8 +42,8 @@ constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
 static size_t chunk_frames() {  // frames per sub-batch: P and X of one chunk should stay in the Infinity Cache
     const char* e = getenv("PVQ_CHUNK_FRAMES");  // developer knob
-    const long v = e ? atol(e) : 16384;
-    return (size_t)(v >= 64 ? v : 16384);
+    const long v = e ? atol(e) : 32768;
+    return (size_t)(v >= 64 ? v : 32768);
 }
 
 struct BlockGroup {
@@ -703,8 +703,9 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         // one launch over the whole batch: the wave-per-frame peak logic is latency-bound and wants as
         // many frames in flight as possible (measured: 8 x 55 us per 8192-frame launch vs 236 us at once)
         slot_begin(SLOT_PEAKS, stream);
-        launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
+        pvq_status ps = launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
         slot_end(SLOT_PEAKS, stream);
+        if (ps != PVQ_OK) return ps;
     }
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_BLOCKDFT;

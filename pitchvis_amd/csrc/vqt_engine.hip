@@ -344,8 +344,37 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int PK_WAVES = 4;
 
+// Common case (min_distance <= 1 and no plateau peak in the frame): the lean routine.  A frame it
+// cannot take is flagged for peaks_frames_generic, which is launched right behind it.
 template <int NK>
-__global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames(const float* __restrict__ db, int n_frames, PeakParamsDev a) {
+__global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
+                                                                       uint8_t* __restrict__ redo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = a.n_bins;
+    const int npad = (n + 63) / 64 * 64;
+    const size_t per_wave = sizeof(float) * (npad + 2 * PK_PAD) + peaks_scratch_bytes(n, 1);
+    float* xs = reinterpret_cast<float*>(pk_smem + wv * per_wave);
+    float* x = xs + PK_PAD;  // x[-PK_PAD..-1] and x[n..npad+PK_PAD-1] hold +INF sentinels
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(xs + npad + 2 * PK_PAD);
+    for (int i = lane; i < PK_PAD; i += 64) xs[i] = __builtin_huge_valf();
+    for (int i = n + lane; i < npad + PK_PAD; i += 64) x[i] = __builtin_huge_valf();
+    for (int frame = blockIdx.x * PK_WAVES + wv; frame < n_frames; frame += gridDim.x * PK_WAVES) {
+        const float* src = db + (size_t)frame * n;
+        for (int i = lane; i < n; i += 64) x[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool done = peaks_wave_lean<NK>(x, scratch, (size_t)frame, a, lane);
+        if (lane == 0) redo[frame] = done ? 0 : 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Generic routine (plateau peaks, min_distance > 1).  redo == nullptr: every frame.
+template <int NK>
+__global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames_generic(const float* __restrict__ db, int n_frames, PeakParamsDev a,
+                                                                     const uint8_t* __restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = a.n_bins;
@@ -354,6 +383,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames(const float* __
     float* x = reinterpret_cast<float*>(pk_smem + wv * per_wave);
     unsigned char* scratch = reinterpret_cast<unsigned char*>(x + npad);
     for (int frame = blockIdx.x * PK_WAVES + wv; frame < n_frames; frame += gridDim.x * PK_WAVES) {
+        if (redo && !redo[frame]) continue;
         const float* src = db + (size_t)frame * n;
         for (int i = lane; i < n; i += 64) x[i] = src[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -420,6 +450,7 @@ Vqt::~Vqt() {
         if (ws_pcm_) (void)hipFree(ws_pcm_);
         if (ws_out_) (void)hipFree(ws_out_);
         if (ws_misc_) (void)hipFree(ws_misc_);
+        if (ws_flags_) (void)hipFree(ws_flags_);
         for (int s = 0; s < N_SLOTS; ++s)
             for (int k = 0; k < 2; ++k)
                 for (hipEvent_t e : ev_[s][k]) (void)hipEventDestroy(e);
@@ -558,8 +589,9 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     slot_end(SLOT_FFT_FRAMES, stream);
     if (pk) {  // peak / note detection as its own launch (one wavefront per frame)
         slot_begin(SLOT_PEAKS, stream);
-        launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
+        pvq_status ps = launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
         slot_end(SLOT_PEAKS, stream);
+        if (ps != PVQ_OK) return ps;
     }
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_FFT;
@@ -651,14 +683,33 @@ pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* o
     return calculate_batch_db(x, 0, plan_.params.n_fft, 1, out_db);
 }
 
-void Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& a, hipStream_t stream) {
+pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& a, hipStream_t stream) {
     const int npad = (a.n_bins + 63) / 64 * 64;
-    const size_t lds = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
     const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
-    if (a.n_bins <= 256)
-        hipLaunchKernelGGL(peaks_frames<4>, dim3(grid), dim3(PK_WAVES * 64), lds, stream, d_db, (int)n_frames, a);
-    else
-        hipLaunchKernelGGL(peaks_frames<16>, dim3(grid), dim3(PK_WAVES * 64), lds, stream, d_db, (int)n_frames, a);
+    const size_t lds_gen = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
+    if (a.dist > 1) {
+        if (a.n_bins <= 256)
+            hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a,
+                               (const uint8_t*)nullptr);
+        else
+            hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a,
+                               (const uint8_t*)nullptr);
+        return PVQ_OK;
+    }
+    pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
+    if (st != PVQ_OK) return st;
+    uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
+    const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_scratch_bytes(a.n_bins, 1));
+    if (a.n_bins <= 256) {
+        hipLaunchKernelGGL(peaks_frames_lean<4>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+        hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(std::min(grid, 512)), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
+                           (int)n_frames, a, (const uint8_t*)redo);  // small grid: it only sweeps the (mostly clear) flags
+    } else {
+        hipLaunchKernelGGL(peaks_frames_lean<16>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+        hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(std::min(grid, 512)), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
+                           (int)n_frames, a, (const uint8_t*)redo);
+    }
+    return PVQ_OK;
 }
 
 pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const AnalysisParameters& ap,
@@ -680,8 +731,9 @@ pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const A
     }
     PVQ_HIP(hipSetDevice(device_id_));
     slot_begin(SLOT_PEAKS, stream);
-    launch_peaks_kernel(d_db, n_frames, a, stream);
+    pvq_status ps = launch_peaks_kernel(d_db, n_frames, a, stream);
     slot_end(SLOT_PEAKS, stream);
+    if (ps != PVQ_OK) return ps;
     PVQ_HIP(hipGetLastError());
     return PVQ_OK;
 }

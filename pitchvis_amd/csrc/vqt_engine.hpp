@@ -85,7 +85,7 @@ class Vqt {
     pvq_status launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
                                     float* d_out_db, float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
     pvq_status ensure_workspace(void** ptr, size_t* cap, size_t bytes);
-    static void launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& p, hipStream_t s);
+    pvq_status launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& p, hipStream_t s);
     void slot_begin(int slot, hipStream_t s);
     void slot_end(int slot, hipStream_t s);
 
@@ -103,6 +103,7 @@ class Vqt {
     void* ws_pcm_ = nullptr;  size_t ws_pcm_cap_ = 0;
     void* ws_out_ = nullptr;  size_t ws_out_cap_ = 0;
     void* ws_misc_ = nullptr; size_t ws_misc_cap_ = 0;
+    void* ws_flags_ = nullptr; size_t ws_flags_cap_ = 0;  // per-frame redo flags of the peak kernels
 };
 
 void set_last_error(const std::string& s);
