@@ -75,6 +75,10 @@ struct BlockDftTables {
     uint16_t* d_row_bin = nullptr; // [n_bins_pad] permuted slot -> bin
     float* d_P = nullptr;  size_t p_cap = 0;   // workspace
     float2* d_X = nullptr; size_t x_cap = 0;
+    // two internal streams so that the MFMA GEMM of sub-batch c+1 overlaps the memory-bound stages of c
+    bool streams_ready = false;
+    hipStream_t s_gemm = nullptr, s_post = nullptr;
+    hipEvent_t ev_gemm[2] = {}, ev_comb[2] = {}, ev_fork = nullptr, ev_join_g = nullptr, ev_join_p = nullptr;
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -90,6 +94,17 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_row_bin) (void)hipFree(t->d_row_bin);
     if (t->d_P) (void)hipFree(t->d_P);
     if (t->d_X) (void)hipFree(t->d_X);
+    if (t->streams_ready) {
+        (void)hipStreamDestroy(t->s_gemm);
+        (void)hipStreamDestroy(t->s_post);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(t->ev_gemm[i]);
+            (void)hipEventDestroy(t->ev_comb[i]);
+        }
+        (void)hipEventDestroy(t->ev_fork);
+        (void)hipEventDestroy(t->ev_join_g);
+        (void)hipEventDestroy(t->ev_join_p);
+    }
     delete t;
 }
 
@@ -588,15 +603,24 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     return PVQ_OK;
 }
 
+// Default: every kernel of a sub-batch on the caller's stream, peaks once over the whole batch.
+// Optional two-stream mode (PVQ_OVERLAP=1), buffers b = c & 1:
+//     s_gemm : [wait combine(c-2) done] GEMM(c) -> P[b]
+//     s_post : [wait GEMM(c) done] combine(c): P[b] -> X[b];  dots(c): X[b] -> out;  (peaks(c))
 pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                      float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     pvq_status st = prepare_blockdft(hop);
     if (st != PVQ_OK) return st;
     BlockDftTables* t = dev_->block;
     const int ntot = t->n_tiles * GM_BN, xc = t->n_tiles * CB_C;
+    // Off by default: measured on MI355X the two streams contend (GEMM 55 -> 90 us, dots 40 -> 91 us per
+    // 8192 frames) and the batch gets slower (1.65 ms vs 1.18 ms per 65 536 frames).  Kept as a developer knob.
+    static const bool overlap_env = getenv("PVQ_OVERLAP") && atoi(getenv("PVQ_OVERLAP"));
+    const bool overlap = overlap_env && n_frames > chunk_frames();
     const size_t chunk = std::min(n_frames, chunk_frames());
     const size_t rows_cap = chunk + t->nb_max - 1;
-    const size_t p_bytes = rows_cap * ntot * sizeof(float), x_bytes = chunk * xc * sizeof(float2);
+    const int n_buf = overlap ? 2 : 1;
+    const size_t p_bytes = rows_cap * ntot * sizeof(float) * n_buf, x_bytes = chunk * xc * sizeof(float2) * n_buf;
     if (t->p_cap < p_bytes) {
         if (t->d_P) PVQ_HIP(hipFree(t->d_P));
         t->d_P = nullptr; t->p_cap = 0;
@@ -609,14 +633,37 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_X), x_bytes));
         t->x_cap = x_bytes;
     }
+    hipStream_t s_gemm = stream, s_post = stream;
+    if (overlap) {
+        if (!t->streams_ready) {
+            PVQ_HIP(hipStreamCreateWithFlags(&t->s_gemm, hipStreamNonBlocking));
+            PVQ_HIP(hipStreamCreateWithFlags(&t->s_post, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                PVQ_HIP(hipEventCreateWithFlags(&t->ev_gemm[i], hipEventDisableTiming));
+                PVQ_HIP(hipEventCreateWithFlags(&t->ev_comb[i], hipEventDisableTiming));
+            }
+            PVQ_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+            PVQ_HIP(hipEventCreateWithFlags(&t->ev_join_g, hipEventDisableTiming));
+            PVQ_HIP(hipEventCreateWithFlags(&t->ev_join_p, hipEventDisableTiming));
+            t->streams_ready = true;
+        }
+        s_gemm = t->s_gemm;
+        s_post = t->s_post;
+        PVQ_HIP(hipEventRecord(t->ev_fork, stream));
+        PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_fork, 0));
+        PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_fork, 0));
+    }
     const long long n_samples = (long long)(n_lead + n_frames * hop);
     const int nb = (int)n_bins();
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
+    const GemmVariant& gv = kGemmVariants[gemm_variant_index()];
     for (size_t c = 0; c < n_chunks; ++c) {
+        const int b = overlap ? (int)(c & 1) : 0;
+        float* P = t->d_P + (size_t)b * rows_cap * ntot;
+        float2* X = t->d_X + (size_t)b * chunk * xc;
         const size_t fbeg = c * chunk;
         const size_t nf = std::min(chunk, n_frames - fbeg);
         const int n_rows = (int)(nf + t->nb_max - 1);
-        const GemmVariant& gv = kGemmVariants[gemm_variant_index()];
         GemmArgs ga;
         // rebase the stream so that every byte offset of this launch fits 32 bits
         const long long first_needed = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop -
@@ -628,53 +675,43 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         ga.pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
         ga.E = t->d_E;
         ga.ld = ntot;
-        ga.P = t->d_P;
+        ga.P = P;
         ga.n_rows = n_rows;
         ga.K = (int)hop;
         ga.tile_s = t->d_tile_s;
         ga.base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
-        slot_begin(SLOT_BLOCKDFT_GEMM, stream);
         ga.n_col_tiles = t->n_tiles * GM_BN / gv.bn;
         ga.p_rows = (int)rows_cap;
         const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
-        hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, stream, ga);
-        slot_end(SLOT_BLOCKDFT_GEMM, stream);
+        if (overlap && c >= 2) PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_comb[b], 0));  // combine(c-2) is done with P[b]
+        slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
+        hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, s_gemm, ga);
+        slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
+        if (overlap) {
+            PVQ_HIP(hipEventRecord(t->ev_gemm[b], s_gemm));
+            PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_gemm[b], 0));
+        }
         CombineArgs ca;
-        ca.P = t->d_P;
+        ca.P = P;
         ca.p_rows = (int)rows_cap;
-        ca.X = t->d_X;
+        ca.X = X;
         ca.xc = xc;
         ca.n_frames = (int)nf;
         ca.n_rows = n_rows;
         ca.tile_group = t->d_tile_group;
         ca.groups = t->d_groups;
         ca.comb_tw = t->d_comb_tw;
-        slot_begin(SLOT_BLOCKDFT_COMBINE, stream);
-        static const int cvar = getenv("PVQ_COMBINE_VARIANT") ? atoi(getenv("PVQ_COMBINE_VARIANT")) : 2;  // developer knob
-        if (t->nb_max <= 64 && cvar == 1)
-            hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256), 0,
-                               stream, ca);
-        else if (t->nb_max <= 64 && cvar == 2)
+        slot_begin(SLOT_BLOCKDFT_COMBINE, s_post);
+        if (t->nb_max <= 64)
             hipLaunchKernelGGL((blockdft_combine<128, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 127) / 128)), dim3(256), 0,
-                               stream, ca);
-        else if (t->nb_max <= 64 && cvar == 3)
-            hipLaunchKernelGGL((blockdft_combine<128, 8, 64>), dim3(t->n_tiles * 4, (unsigned)((nf + 127) / 128)), dim3(256), 0,
-                               stream, ca);
-        else if (t->nb_max <= 64 && cvar == 4)
-            hipLaunchKernelGGL((blockdft_combine<256, 8, 64>), dim3(t->n_tiles * 4, (unsigned)((nf + 255) / 256)), dim3(256), 0,
-                               stream, ca);
-        else if (t->nb_max <= 64 && cvar == 5)
-            hipLaunchKernelGGL((blockdft_combine<256, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 255) / 256)), dim3(256), 0,
-                               stream, ca);
-        else if (t->nb_max <= 64)
-            hipLaunchKernelGGL((blockdft_combine<CB_T, 32, 64>), dim3(t->n_tiles, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256), 0,
-                               stream, ca);
+                               s_post, ca);
         else
             hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 256>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256),
-                               0, stream, ca);
-        slot_end(SLOT_BLOCKDFT_COMBINE, stream);
+                               0, s_post, ca);
+        slot_end(SLOT_BLOCKDFT_COMBINE, s_post);
+        if (overlap) PVQ_HIP(hipEventRecord(t->ev_comb[b], s_post));
         DotsArgs da;
-        da.X = t->d_X;
+        da.X = X;
         da.xc = xc;
         da.n_frames = (int)nf;
         da.n_bins = nb;
@@ -685,23 +722,30 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.row_bin = t->d_row_bin;
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
-        static const int dfb = getenv("PVQ_DOTS_FB") ? atoi(getenv("PVQ_DOTS_FB")) : 4;  // developer knob
-        slot_begin(SLOT_BLOCKDFT_DOTS, stream);
-        if (dfb == 2) {
-            const size_t lds = sizeof(float2) * 2 * xc + sizeof(float) * 2 * 2 * 4;
-            hipLaunchKernelGGL(blockdft_dots_db<2>, dim3((unsigned)((nf + 1) / 2)), dim3(256), lds, stream, da);
-        } else if (dfb == 8) {
-            const size_t lds = sizeof(float2) * 8 * xc + sizeof(float) * 2 * 8 * 4;
-            hipLaunchKernelGGL(blockdft_dots_db<8>, dim3((unsigned)((nf + 7) / 8)), dim3(256), lds, stream, da);
-        } else {
-            const size_t lds = sizeof(float2) * 4 * xc + sizeof(float) * 2 * 4 * 4;
-            hipLaunchKernelGGL(blockdft_dots_db<4>, dim3((unsigned)((nf + 3) / 4)), dim3(256), lds, stream, da);
+        const size_t lds = sizeof(float2) * 4 * xc + sizeof(float) * 2 * 4 * 4;
+        slot_begin(SLOT_BLOCKDFT_DOTS, s_post);
+        hipLaunchKernelGGL(blockdft_dots_db<4>, dim3((unsigned)((nf + 3) / 4)), dim3(256), lds, s_post, da);
+        slot_end(SLOT_BLOCKDFT_DOTS, s_post);
+        if (pk && overlap) {
+            // peaks of this sub-batch right behind its dB rows, beside the next sub-batch's GEMM
+            PeakParamsDev p2 = *pk;
+            const size_t words = (nb + 31) / 32;
+            if (p2.mask) p2.mask += fbeg * words;
+            if (p2.count) p2.count += fbeg;
+            if (p2.center) p2.center += fbeg * p2.max_peaks;
+            if (p2.size) p2.size += fbeg * p2.max_peaks;
+            slot_begin(SLOT_PEAKS, s_post);
+            pvq_status ps = launch_peaks_kernel(d_out_db + fbeg * nb, nf, p2, s_post);
+            slot_end(SLOT_PEAKS, s_post);
+            if (ps != PVQ_OK) return ps;
         }
-        slot_end(SLOT_BLOCKDFT_DOTS, stream);
     }
-    if (pk) {
-        // one launch over the whole batch: the wave-per-frame peak logic is latency-bound and wants as
-        // many frames in flight as possible (measured: 8 x 55 us per 8192-frame launch vs 236 us at once)
+    if (overlap) {
+        PVQ_HIP(hipEventRecord(t->ev_join_g, s_gemm));
+        PVQ_HIP(hipEventRecord(t->ev_join_p, s_post));
+        PVQ_HIP(hipStreamWaitEvent(stream, t->ev_join_g, 0));
+        PVQ_HIP(hipStreamWaitEvent(stream, t->ev_join_p, 0));
+    } else if (pk) {
         slot_begin(SLOT_PEAKS, stream);
         pvq_status ps = launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
         slot_end(SLOT_PEAKS, stream);
