@@ -19,12 +19,12 @@ from typing import List, Optional
 import numpy as np
 
 from . import _lib
-from ._lib import ALGO_AUTO, ALGO_BLOCKDFT, ALGO_FFT  # noqa: F401
+from ._lib import ALGO_AUTO, ALGO_BLOCKDFT, ALGO_FFT, GEMM_BF16X3, GEMM_F32  # noqa: F401
 
 __all__ = [
     "VqtRange", "VqtParameters", "VqtError", "AboveNyquist", "WindowExceedsNFft", "PvqError", "WindowGroup",
     "VqtKernel", "Vqt", "PeakDetectionParameters", "AnalysisParameters", "ContinuousPeak", "FrameAnalysis",
-    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT",
+    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT", "GEMM_F32", "GEMM_BF16X3",
 ]
 
 
@@ -342,6 +342,10 @@ class Vqt:
     # ---- knobs ---------------------------------------------------------------------------------
     def set_algo(self, algo: int) -> None:
         _check(self._L.pvq_vqt_set_algo(self._h, algo))
+
+    def set_gemm_precision(self, precision: int) -> None:
+        """GEMM_F32 (exact fp32 MFMA, default) or GEMM_BF16X3 (split-bf16 on the bf16 matrix cores)"""
+        _check(self._L.pvq_vqt_set_gemm_precision(self._h, precision))
 
     def last_algo(self) -> int:
         return self._L.pvq_vqt_last_algo(self._h)

@@ -185,6 +185,16 @@ pvq_status pvq_vqt_set_algo(pvq_vqt* v, pvq_algo algo) {
 }
 pvq_algo pvq_vqt_last_algo(const pvq_vqt* v) { return v ? v->impl->last_algo() : PVQ_ALGO_AUTO; }
 
+pvq_status pvq_vqt_set_gemm_precision(pvq_vqt* v, pvq_gemm_precision p) {
+    if (!v) return null_handle();
+    if (p != PVQ_GEMM_F32 && p != PVQ_GEMM_BF16X3) {
+        pvq::set_last_error("unknown GEMM precision");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    v->impl->set_gemm_split_bf16(p == PVQ_GEMM_BF16X3);
+    return PVQ_OK;
+}
+
 void pvq_analysis_default_params(pvq_analysis_params* a) {
     if (!a) return;
     const pvq::AnalysisParameters d;

@@ -64,7 +64,9 @@ struct BlockDftTables {
     int ell_len = 0;   // max entries per output row
     int n_bins_pad = 0;
     std::vector<BlockGroup> groups;
+    std::vector<float> h_E;        // host copy of E
     float* d_E = nullptr;          // [hop][Ntot]
+    __bf16* d_Et = nullptr;        // [3][Ntot][hop] hi/mid/lo bf16 planes of E^T (split-bf16 GEMM), built on first use
     int* d_tile_group = nullptr;   // [n_tiles]
     long long* d_tile_s = nullptr; // [n_tiles] window begin of the tile's group relative to the buffer end
     BlockGroup* d_groups = nullptr;
@@ -84,6 +86,7 @@ struct BlockDftTables {
 void free_blockdft_tables(BlockDftTables* t) {
     if (!t) return;
     if (t->d_E) (void)hipFree(t->d_E);
+    if (t->d_Et) (void)hipFree(t->d_Et);
     if (t->d_tile_group) (void)hipFree(t->d_tile_group);
     if (t->d_tile_s) (void)hipFree(t->d_tile_s);
     if (t->d_groups) (void)hipFree(t->d_groups);
@@ -222,6 +225,144 @@ __global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = j0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a.n_rows) a.P[((size_t)(col >> 6) * a.p_rows + row) * 64 + (col & 63)] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 form of the same GEMM ("bf16x3", optional: pvq_vqt_set_gemm_precision): each fp32
+// operand is written exactly as hi + mid + lo with three bf16 values (8+8+8 mantissa bits) and the
+// product is accumulated in fp32 from the six partial products whose weight is >= 2^-16 (hh, hm, mh,
+// hl, lh, mm); the dropped terms are below 2^-24 of the product, i.e. at fp32 rounding level, and every
+// partial product of two bf16 numbers is exact in fp32.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate
+// of the fp32 MFMA, so six of them replace eight fp32 MFMAs at 6/16 of the matrix-pipe time.  E is split
+// once on the host (planes stored [plane][n][k], k contiguous = the B-operand fragment order); the PCM
+// tile is split while it is staged.  Measured: accuracy equal to the fp32 MFMA path (2.5-3.5e-7 of the
+// frame peak) but only ~1.2x faster — staging three bf16 planes of A through LDS (ds_write at
+// <= 80 B/clk/CU) is what bounds it, not the matrix pipe.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct GemmBfArgs {
+    const float* pcm_base;
+    unsigned pcm_bytes;
+    const __bf16* Et;         // [3][Ntot][K]
+    int ntot;
+    float* P;
+    int n_rows;
+    int K;
+    const long long* tile_s;
+    long long base;
+    int n_col_tiles;
+    int p_rows;
+};
+
+constexpr int BF_BM = 256, BF_BN = 64, BF_BK = 32, BF_LD = BF_BK + 8;  // LDS row stride in bf16 (80 B: 16-B aligned)
+
+__global__ __launch_bounds__(256) void blockdft_gemm_bf16x3(GemmBfArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BF_BM][BF_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BF_BN][BF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, bi = b >> 3;
+    const int nt = bi % a.n_col_tiles;
+    const int mt = (bi / a.n_col_tiles) * 8 + xcd;
+    if (mt * BF_BM >= a.n_rows) return;
+    const int j0 = mt * BF_BM;
+    const long long s = a.base + a.tile_s[nt];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+
+    // A staging: thread -> (row = tid/16 + 16*i, pair of k = 2*(tid%16)), 16 passes cover 256 rows x 32 k
+    constexpr int A_PASSES = BF_BM * BF_BK / 2 / 256;  // 16
+    const int a_row = tid >> 4, a_k = (tid & 15) * 2;
+    const unsigned a_off0 = (unsigned)((s + (long long)(j0 + a_row) * a.K + a_k) * 4ll);
+    const unsigned a_pass = (unsigned)(16 * a.K * 4);
+    float ra[A_PASSES][2];
+    // B staging: per plane 64 rows(n) x 32 k bf16 = 64 x 64 B: thread -> (n = tid/4, 16-B chunk = tid%4), 3 planes
+    const int b_n = tid >> 2, b_c = (tid & 3) * 8;
+    bf16x8 rb[3];
+    const size_t plane = (size_t)a.ntot * a.K;
+    const __bf16* e_ptr = a.Et + (size_t)(nt * BF_BN + b_n) * a.K + b_c;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_iter = a.K / BF_BK;
+    const int ar = wave * 64 + (lane & 31);  // wave tile: rows wave*64 .. +63, all 64 columns
+    const int kh = (lane >> 5) * 8;
+#define PVQ_BF_LOAD(k0)                                                                                          \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                   \
+            const unsigned off = a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u;                              \
+            ra[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));         \
+            ra[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4u, 0, 0));    \
+        }                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const bf16x8*>(e_ptr + p * plane + (k0)); \
+    }
+#define PVQ_BF_STORE()                                                                                           \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                   \
+            const float x0 = ra[i][0], x1 = ra[i][1];                                                            \
+            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;                                                       \
+            const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;                                                \
+            const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;                                                       \
+            const __bf16 l0 = (__bf16)(r0 - (float)m0), l1 = (__bf16)(r1 - (float)m1);                           \
+            bf16x2 vh = {h0, h1}, vm = {m0, m1}, vl = {l0, l1};                                                  \
+            *reinterpret_cast<bf16x2*>(&As[0][a_row + 16 * i][a_k]) = vh;                                        \
+            *reinterpret_cast<bf16x2*>(&As[1][a_row + 16 * i][a_k]) = vm;                                        \
+            *reinterpret_cast<bf16x2*>(&As[2][a_row + 16 * i][a_k]) = vl;                                        \
+        }                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(&Bs[p][b_n][b_c]) = rb[p];      \
+    }
+
+    PVQ_BF_LOAD(0);
+    for (int it = 0; it < n_iter; ++it) {
+        PVQ_BF_STORE();
+        __syncthreads();
+        if (it + 1 < n_iter) PVQ_BF_LOAD((it + 1) * BF_BK);
+#pragma unroll
+        for (int kk = 0; kk < BF_BK / 16; ++kk) {
+            bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(&As[p][ar + 32 * i][kk * 16 + kh]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[p][(lane & 31) + 32 * j][kk * 16 + kh]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][1], acc[i][j], 0, 0, 0);  // mid*mid
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][2], acc[i][j], 0, 0, 0);  // hi*lo
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[j][0], acc[i][j], 0, 0, 0);  // lo*hi
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], acc[i][j], 0, 0, 0);  // hi*mid
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][0], acc[i][j], 0, 0, 0);  // mid*hi
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);  // hi*hi
+                }
+        }
+        __syncthreads();
+    }
+#undef PVQ_BF_LOAD
+#undef PVQ_BF_STORE
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = nt * BF_BN + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = j0 + wave * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < a.n_rows) a.P[((size_t)(col >> 6) * a.p_rows + row) * 64 + (col & 63)] = acc[i][j][r];
             }
         }
@@ -591,6 +732,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     std::vector<long long> tile_s(tile, 0);
     for (size_t g = 0; g < groups.size(); ++g)
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
+    t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_ell_val, ell_val) && up(&t->d_ell_col, ell_col) &&
               up(&t->d_row_len, row_len) && up(&t->d_row_bin, row_bin);
@@ -654,6 +796,35 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_fork, 0));
     }
     const long long n_samples = (long long)(n_lead + n_frames * hop);
+    const bool use_bf = gemm_split_bf16_ && hop % BF_BK == 0;
+    if (use_bf && !t->d_Et) {
+        // bf16 split of E^T (round-to-nearest-even on the bit patterns), built on first use
+        auto to_bf16 = [](float f) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);   // E holds finite values in [-1, 1]
+            return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t h) -> float {
+            uint32_t u = (uint32_t)h << 16;
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        std::vector<uint16_t> Et((size_t)3 * ntot * hop);
+        for (int n = 0; n < ntot; ++n)
+            for (size_t m = 0; m < hop; ++m) {
+                const float x = t->h_E[m * ntot + n];
+                const uint16_t h = to_bf16(x);
+                const float r1 = x - from_bf16(h);
+                const uint16_t mid = to_bf16(r1);
+                Et[((size_t)0 * ntot + n) * hop + m] = h;
+                Et[((size_t)1 * ntot + n) * hop + m] = mid;
+                Et[((size_t)2 * ntot + n) * hop + m] = to_bf16(r1 - from_bf16(mid));
+            }
+        PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_Et), Et.size() * 2));
+        PVQ_HIP(hipMemcpy(t->d_Et, Et.data(), Et.size() * 2, hipMemcpyHostToDevice));
+    }
     const int nb = (int)n_bins();
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     const GemmVariant& gv = kGemmVariants[gemm_variant_index()];
@@ -685,7 +856,24 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
         if (overlap && c >= 2) PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_comb[b], 0));  // combine(c-2) is done with P[b]
         slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
-        hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, s_gemm, ga);
+        if (use_bf) {
+            GemmBfArgs gb;
+            gb.pcm_base = ga.pcm_base;
+            gb.pcm_bytes = ga.pcm_bytes;
+            gb.Et = t->d_Et;
+            gb.ntot = ntot;
+            gb.P = P;
+            gb.n_rows = n_rows;
+            gb.K = (int)hop;
+            gb.tile_s = t->d_tile_s;
+            gb.base = ga.base;
+            gb.n_col_tiles = t->n_tiles;
+            gb.p_rows = (int)rows_cap;
+            const int mt8 = (((n_rows + BF_BM - 1) / BF_BM) + 7) / 8 * 8;
+            hipLaunchKernelGGL(blockdft_gemm_bf16x3, dim3(gb.n_col_tiles * mt8), dim3(256), 0, s_gemm, gb);
+        } else {
+            hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, s_gemm, ga);
+        }
         slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
         if (overlap) {
             PVQ_HIP(hipEventRecord(t->ev_gemm[b], s_gemm));

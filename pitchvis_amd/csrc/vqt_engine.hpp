@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -60,6 +61,9 @@ class Vqt {
                              uint32_t* peak_count, float* center, float* size, uint32_t max_peaks);
 
     void set_algo(pvq_algo a) { algo_ = a; }
+    // block-DFT GEMM arithmetic: exact fp32 MFMA, or the split-bf16 (3 x bf16, fp32 accumulate) form
+    void set_gemm_split_bf16(bool on) { gemm_split_bf16_ = on; }
+    bool gemm_split_bf16() const { return gemm_split_bf16_; }
     pvq_algo last_algo() const { return last_algo_; }
     // HIP-event timing of every kernel launch (per slot) on the stream it is launched on.
     // Enabling resets the statistics; last_kernel_ms reports the mean per launch since then.
@@ -95,6 +99,7 @@ class Vqt {
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
     bool profiling_ = false;
+    bool gemm_split_bf16_ = false;
     uint32_t last_frames_per_launch_ = 0;
     static constexpr int kMaxTimedLaunches = 512;
     std::vector<hipEvent_t> ev_[N_SLOTS][2];  // event pool, grown on demand

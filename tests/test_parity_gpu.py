@@ -32,14 +32,25 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALGOS = [P.ALGO_FFT, P.ALGO_BLOCKDFT]
+ALGOS = [P.ALGO_FFT, P.ALGO_BLOCKDFT, "blockdft_bf16x3"]
+
+
+def _set_algo(v, algo):
+    """algo is a pvq_algo value, or 'blockdft_bf16x3' = block-DFT path with the split-bf16 GEMM"""
+    if algo == "blockdft_bf16x3":
+        v.set_algo(P.ALGO_BLOCKDFT)
+        v.set_gemm_precision(P.GEMM_BF16X3)
+        return P.ALGO_BLOCKDFT
+    v.set_algo(algo)
+    v.set_gemm_precision(P.GEMM_F32)
+    return algo
 
 
 def _applicable(v, algo, hop, nf):
     if algo == P.ALGO_FFT:
         return True
     try:
-        v.set_algo(algo)
+        _set_algo(v, algo)
         d = torch.zeros(hop * 64 + 40000, device="cuda")
         o = torch.empty((64, v.n_bins), device="cuda")
         v.calculate_batch_db_device(d, hop, 64, o, n_lead=40000)
@@ -110,10 +121,10 @@ def test_batch_parity_noise(name, algo):
     nf, n_lead = 72, 33000
     if not _applicable(v, algo, hop, nf):
         pytest.skip("block-DFT path not applicable to this geometry/hop")
-    v.set_algo(algo)
+    algo_id = _set_algo(v, algo)
     pcm = white_noise(n_lead + hop * nf, 0x5EED0001)
     db, cx = run_gpu(v, pcm, hop, nf, n_lead)
-    assert v.last_algo() == algo
+    assert v.last_algo() == algo_id
     wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
     truth = MF.from_oracle_params(op, values_from=ov).batch_complex(pcm, hop, 8, n_lead=n_lead)
     assert_parity(db[:8], cx[:8], wdb[:8], wcx[:8], truth)
@@ -130,7 +141,7 @@ def test_three_regimes_and_stream_start(algo):
     hop, nf = 256, 384
     if not _applicable(v, algo, hop, nf):
         pytest.skip("not applicable")
-    v.set_algo(algo)
+    _set_algo(v, algo)
     pcm = three_regime(hop * nf, op.sr, 3)
     db, cx = run_gpu(v, pcm, hop, nf, 0)
     wdb, wcx = ov.calculate_batch(pcm, hop, nf, want_complex=True)
@@ -151,7 +162,7 @@ def test_sweep_parity(algo):
     hop, nf = 256, 375  # BASELINE config 1: 2.000 s at 48 kHz
     if not _applicable(v, algo, hop, nf):
         pytest.skip("not applicable")
-    v.set_algo(algo)
+    _set_algo(v, algo)
     pcm = sine_sweep(hop * nf, op.sr)
     db, cx = run_gpu(v, pcm, hop, nf, 0)
     wdb, wcx = ov.calculate_batch(pcm, hop, nf, want_complex=True)
@@ -203,7 +214,7 @@ def test_golden_fixtures(algo):
     hop, nf, n_lead = int(z["hop"]), int(z["n_frames"]), int(z["n_lead"])
     if not _applicable(v, algo, hop, 64):
         pytest.skip("not applicable")
-    v.set_algo(algo)
+    _set_algo(v, algo)
     for case in ("noise", "regimes"):
         db, cx = run_gpu(v, z[f"{case}_pcm"], hop, nf, n_lead)
         keep = np.abs(z[f"{case}_cplx"]).max(axis=1) > 0
@@ -228,7 +239,7 @@ def test_full_size_properties(algo):
     hop, nf = 256, 65536
     if not _applicable(v, algo, hop, nf):
         pytest.skip("not applicable")
-    v.set_algo(algo)
+    _set_algo(v, algo)
     g = torch.Generator(device="cuda"); g.manual_seed(0x5EED0001)
     d_pcm = (torch.rand(hop * nf, device="cuda", generator=g) - 0.5) * 0.5
     d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
