@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--frames", type=int, default=65536, help="frames (hops) per GPU per step")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "blockdft"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the plumbing on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,13 +120,14 @@ def main():
     import pitchvis_amd as P
     from pitchvis_amd.sharding import plan_shard
 
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)   # identity on an N-GPU node
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, 7, 36))
-    vqt = P.Vqt.new(params, device=local_rank)
+    vqt = P.Vqt.new(params, device=device_index)
     vqt.set_algo({"auto": P.ALGO_AUTO, "fft": P.ALGO_FFT, "blockdft": P.ALGO_BLOCKDFT}[args.algo])
     assert vqt.n_bins == N_BINS
 
@@ -167,7 +170,7 @@ def main():
     fpl = vqt.last_frames_per_launch()
     vqt.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -224,10 +227,15 @@ def main():
                 "frac": round(tflops / PEAK_FP32_TFLOPS, 5),
                 "traffic": traffic,
                 "alg_flop_per_frame": F_ALG_FLOP_PER_FRAME,
+                "note": "achieved = algorithmic flop (FFT-route count, SURVEY 8d) x frames per launch / mean launch time of "
+                        "the kernel with the largest GPU time; the block-DFT path executes fewer flop than that count "
+                        "(hop blocks are shared by up to 64 frames), see executed_gemm_tflops and DESIGN.md 4-5",
                 "frames_per_launch": fpl,
                 "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "launches_per_step": {k: kernel_n.get(k, 0) // args.steps for k in kernel_ms},
                 "gpu_ms_per_step_all_kernels": round(gpu_ms_per_step, 4),
+                "executed_gemm_tflops": (round(2.0 * HOP * 2 * vqt.blockdft_columns() * fpl / (kernel_ms["blockdft_gemm"] * 1e-3) / 1e12, 2)
+                                         if "blockdft_gemm" in kernel_ms and vqt.blockdft_columns() else None),
                 # whole path (all kernels of a step) against the same fp32 roof
                 "path_tflops": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12, 3),
                 "path_frac": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 5),

@@ -139,6 +139,8 @@ typedef enum pvq_gemm_precision {
     PVQ_GEMM_BF16X3 = 1   /* split-bf16: 6 bf16 MFMAs per fp32 product block, error at fp32 rounding level */
 } pvq_gemm_precision;
 pvq_status pvq_vqt_set_gemm_precision(pvq_vqt *v, pvq_gemm_precision p);
+/* complex spectrum columns per hop block the block-DFT GEMM computes (padded), 0 before its first use */
+uint32_t pvq_vqt_blockdft_columns(const pvq_vqt *v);
 
 /* ---- peak / note detection: analysis_modules/peak_detection.rs + analysis.rs:332-361 ---- */
 

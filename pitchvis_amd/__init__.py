@@ -347,6 +347,9 @@ class Vqt:
         """GEMM_F32 (exact fp32 MFMA, default) or GEMM_BF16X3 (split-bf16 on the bf16 matrix cores)"""
         _check(self._L.pvq_vqt_set_gemm_precision(self._h, precision))
 
+    def blockdft_columns(self) -> int:
+        return int(self._L.pvq_vqt_blockdft_columns(self._h))
+
     def last_algo(self) -> int:
         return self._L.pvq_vqt_last_algo(self._h)
 

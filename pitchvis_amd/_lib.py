@@ -16,7 +16,7 @@ EXPORTS = [
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
-    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision",
+    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_blockdft_columns",
 ]
 
 PVQ_OK = 0
@@ -101,6 +101,7 @@ def load():
     L.pvq_vqt_calculate_batch_db_device.restype = C.c_int
     L.pvq_vqt_set_algo.argtypes = [vp, C.c_int]; L.pvq_vqt_set_algo.restype = C.c_int
     L.pvq_vqt_last_algo.argtypes = [vp]; L.pvq_vqt_last_algo.restype = C.c_int
+    L.pvq_vqt_blockdft_columns.argtypes = [vp]; L.pvq_vqt_blockdft_columns.restype = C.c_uint32
     L.pvq_vqt_set_gemm_precision.argtypes = [vp, C.c_int]; L.pvq_vqt_set_gemm_precision.restype = C.c_int
     L.pvq_analysis_default_params.argtypes = [C.POINTER(CAnalysisParams)]
     L.pvq_analyze_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(CAnalysisParams), vp, vp, vp, vp, C.c_uint32, vp]

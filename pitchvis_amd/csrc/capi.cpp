@@ -185,6 +185,8 @@ pvq_status pvq_vqt_set_algo(pvq_vqt* v, pvq_algo algo) {
 }
 pvq_algo pvq_vqt_last_algo(const pvq_vqt* v) { return v ? v->impl->last_algo() : PVQ_ALGO_AUTO; }
 
+uint32_t pvq_vqt_blockdft_columns(const pvq_vqt* v) { return v ? v->impl->blockdft_columns() : 0; }
+
 pvq_status pvq_vqt_set_gemm_precision(pvq_vqt* v, pvq_gemm_precision p) {
     if (!v) return null_handle();
     if (p != PVQ_GEMM_F32 && p != PVQ_GEMM_BF16X3) {

@@ -588,6 +588,8 @@ __global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_t)(dev_->block->n_tiles * CB_C) : 0u; }
+
 bool Vqt::blockdft_applicable(size_t hop) const {
     if (!has_device() || hop < 32 || (hop & (hop - 1)) != 0 || hop > 4096) return false;
     if (n_bins() > 1024) return false;

@@ -64,6 +64,7 @@ class Vqt {
     // block-DFT GEMM arithmetic: exact fp32 MFMA, or the split-bf16 (3 x bf16, fp32 accumulate) form
     void set_gemm_split_bf16(bool on) { gemm_split_bf16_ = on; }
     bool gemm_split_bf16() const { return gemm_split_bf16_; }
+    uint32_t blockdft_columns() const;
     pvq_algo last_algo() const { return last_algo_; }
     // HIP-event timing of every kernel launch (per slot) on the stream it is launched on.
     // Enabling resets the statistics; last_kernel_ms reports the mean per launch since then.
