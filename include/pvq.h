@@ -183,6 +183,57 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt *v, const float *d_pcm, size_t n
                                         uint32_t *d_peak_count, float *d_center, float *d_size,
                                         uint32_t max_peaks, void *stream);
 
+
+/* ---- stateful per-stream analysis: AnalysisState (analysis.rs:119-410), host side ------------------
+ * preprocess() is a recurrence over frames (bin EMAs, calmness EMAs and the scene calmness feed the
+ * next frame's smoothing horizons: analysis.rs:295-319, calmness.rs:23-95), so it is sequential per
+ * stream and runs on the host, fed with dB frames computed on the GPU.  One handle per stream. */
+
+/* replaces AnalysisParameters (analysis.rs:36-65), Default at :72-98; durations in nanoseconds */
+typedef struct pvq_analysis_full_params {
+    uint32_t spectrogram_length;                       /* 400 (unused by the crate itself) */
+    float peak_min_prominence, peak_min_height;        /* peak_config 10.0 / 4.0 */
+    float bass_min_prominence, bass_min_height;        /* bassline_peak_config 5.0 / 3.5 */
+    uint32_t highest_bassnote;                         /* 28 */
+    uint64_t vqt_smoothing_duration_base_ns;           /* 70 ms */
+    float vqt_smoothing_calmness_min, vqt_smoothing_calmness_max;  /* 0.6 / 2.0 */
+    uint64_t note_calmness_smoothing_duration_ns;      /* 3500 ms */
+    uint64_t scene_calmness_smoothing_duration_ns;     /* 800 ms */
+    uint64_t tuning_inaccuracy_smoothing_duration_ns;  /* 4000 ms */
+    float harmonic_threshold;                          /* 0.3 */
+} pvq_analysis_full_params;
+void pvq_analysis_full_default_params(pvq_analysis_full_params *p);
+
+typedef struct pvq_analysis_state pvq_analysis_state;
+/* replaces AnalysisState::new(range, params) (analysis.rs:192) */
+pvq_status pvq_analysis_state_create(float min_freq, uint32_t octaves, uint32_t buckets_per_octave,
+                                     const pvq_analysis_full_params *params, pvq_analysis_state **out);
+void pvq_analysis_state_destroy(pvq_analysis_state *s);
+/* replaces update_vqt_smoothing_duration(Option<Duration>) (analysis.rs:251); has_duration = 0 is None */
+pvq_status pvq_analysis_state_update_vqt_smoothing_duration(pvq_analysis_state *s, int has_duration, uint64_t duration_ns);
+/* replaces preprocess(&[f32], Duration) (analysis.rs:288); a wrong length returns PVQ_ERR_BAD_LENGTH
+ * where the reference panics (analysis.rs:289) */
+pvq_status pvq_analysis_state_preprocess(pvq_analysis_state *s, const float *x_vqt, size_t len, uint64_t frame_time_ns);
+/* replaces bin_to_frequency (analysis.rs:407) */
+float pvq_analysis_state_bin_to_frequency(const pvq_analysis_state *s, uint32_t bin);
+
+/* the `pub` result fields (analysis.rs:119-177); arrays have n_buckets entries */
+typedef enum pvq_analysis_field {
+    PVQ_FIELD_X_VQT_SMOOTHED = 0,  /* x_vqt_smoothed[i].get() */
+    PVQ_FIELD_X_VQT_PEAKFILTERED = 1,
+    PVQ_FIELD_X_VQT_AFTERGLOW = 2,
+    PVQ_FIELD_CALMNESS = 3,        /* calmness[i].get() */
+    PVQ_FIELD_PITCH_ACCURACY = 4,
+    PVQ_FIELD_PITCH_DEVIATION = 5
+} pvq_analysis_field;
+uint32_t pvq_analysis_state_n_buckets(const pvq_analysis_state *s);
+pvq_status pvq_analysis_state_get_field(const pvq_analysis_state *s, pvq_analysis_field f, float *out);
+/* peaks (ascending bin indices) and peaks_continuous (ascending center); return the total count */
+uint32_t pvq_analysis_state_get_peaks(const pvq_analysis_state *s, uint32_t *out, uint32_t capacity);
+uint32_t pvq_analysis_state_get_peaks_continuous(const pvq_analysis_state *s, float *center, float *size, uint32_t capacity);
+float pvq_analysis_state_scene_calmness(const pvq_analysis_state *s);            /* smoothed_scene_calmness.get() */
+float pvq_analysis_state_tuning_grid_inaccuracy(const pvq_analysis_state *s);    /* smoothed_tuning_grid_inaccuracy.get() */
+
 /* timing hook for bench.py: elapsed GPU milliseconds of the dominant kernel launches of the
  * last batch call, measured with HIP events on the stream the kernels were launched on.
  * Enable with pvq_vqt_set_profiling(v, 1) (resets the statistics); reading synchronises. */

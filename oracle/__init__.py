@@ -88,6 +88,8 @@ def lib():
         L.orc_analyze_frame.argtypes = [fp, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
                                         C.POINTER(_AParams), up, fp, fp]
         L.orc_analyze_frame.restype = C.c_uint32
+        L.orc_expf.argtypes = [C.c_float]; L.orc_expf.restype = C.c_float
+        L.orc_powf.argtypes = [C.c_float, C.c_float]; L.orc_powf.restype = C.c_float
         L.orc_fft_complex.argtypes = [fp, C.c_uint32, C.c_int]
         L.orc_fft_real.argtypes = [fp, C.c_uint32, fp]
         _lib = L
@@ -306,3 +308,11 @@ def fft_real(x):
     out = np.empty(x.size // 2 + 1, np.complex64)
     lib().orc_fft_real(_f(x), x.size, out.view(np.float32).ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def expf(x) -> np.float32:
+    return np.float32(lib().orc_expf(float(np.float32(x))))
+
+
+def powf(x, y) -> np.float32:
+    return np.float32(lib().orc_powf(float(np.float32(x)), float(np.float32(y))))

@@ -788,3 +788,8 @@ uint32_t orc_analyze_frame(const float *vqt, uint32_t n, float min_freq, uint32_
                                           a->highest_bassnote, a->harmonic_threshold);
     return np;
 }
+
+/* libm pass-throughs so that the NumPy-side restatement of AnalysisState (oracle/analysis_state.py)
+ * evaluates exp / pow with the same glibc routines the reference's f32::exp / f32::powf resolve to */
+float orc_expf(float x) { return expf(x); }
+float orc_powf(float x, float y) { return powf(x, y); }

@@ -126,6 +126,10 @@ uint32_t orc_analyze_frame(const float *vqt, uint32_t n, float min_freq, uint32_
                            uint32_t buckets_per_octave, const orc_analysis_params *a,
                            uint32_t *out_idx, float *out_center, float *out_size);
 
+/* glibc expf / powf (used by oracle/analysis_state.py) */
+float orc_expf(float x);
+float orc_powf(float x, float y);
+
 /* FFT contracts (vqt.rs:1087-1128): unnormalised complex forward/inverse, R2C */
 void orc_fft_complex(float *re_im_interleaved, uint32_t n, int inverse);
 void orc_fft_real(const float *x, uint32_t n, float *out_cplx /* n/2+1 */);

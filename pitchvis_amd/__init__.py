@@ -24,7 +24,7 @@ from ._lib import ALGO_AUTO, ALGO_BLOCKDFT, ALGO_FFT, GEMM_BF16X3, GEMM_F32  # n
 __all__ = [
     "VqtRange", "VqtParameters", "VqtError", "AboveNyquist", "WindowExceedsNFft", "PvqError", "WindowGroup",
     "VqtKernel", "Vqt", "PeakDetectionParameters", "AnalysisParameters", "ContinuousPeak", "FrameAnalysis",
-    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT", "GEMM_F32", "GEMM_BF16X3",
+    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT", "GEMM_F32", "GEMM_BF16X3", "AnalysisState", "FullAnalysisParameters",
 ]
 
 
@@ -369,3 +369,109 @@ class Vqt:
 
     def last_frames_per_launch(self) -> int:
         return int(self._L.pvq_vqt_last_frames_per_launch(self._h))
+
+
+# ---- analysis.rs:35-98, 119-410: stateful per-stream analysis (host side) ---------------------------
+@dataclass
+class FullAnalysisParameters:
+    """AnalysisParameters of the reference (analysis.rs:36-65, Default :72-98); durations in seconds."""
+    spectrogram_length: int = 400
+    peak_config: PeakDetectionParameters = field(default_factory=lambda: PeakDetectionParameters(10.0, 4.0))
+    bassline_peak_config: PeakDetectionParameters = field(default_factory=lambda: PeakDetectionParameters(5.0, 3.5))
+    highest_bassnote: int = 12 * 2 + 4
+    vqt_smoothing_duration_base: float = 0.070
+    vqt_smoothing_calmness_min: float = 0.6
+    vqt_smoothing_calmness_max: float = 2.0
+    note_calmness_smoothing_duration: float = 3.5
+    scene_calmness_smoothing_duration: float = 0.8
+    tuning_inaccuracy_smoothing_duration: float = 4.0
+    harmonic_threshold: float = 0.3
+
+    def _c(self) -> _lib.CAnalysisFullParams:
+        ns = lambda s: int(round(s * 1e9))
+        return _lib.CAnalysisFullParams(
+            self.spectrogram_length, self.peak_config.min_prominence, self.peak_config.min_height,
+            self.bassline_peak_config.min_prominence, self.bassline_peak_config.min_height, self.highest_bassnote,
+            ns(self.vqt_smoothing_duration_base), self.vqt_smoothing_calmness_min, self.vqt_smoothing_calmness_max,
+            ns(self.note_calmness_smoothing_duration), ns(self.scene_calmness_smoothing_duration),
+            ns(self.tuning_inaccuracy_smoothing_duration), self.harmonic_threshold)
+
+
+class AnalysisState:
+    """Mirror of pitchvis_analysis::analysis::AnalysisState.  The frame-to-frame recurrence (EMA smoothing,
+    calmness feedback, afterglow, tuning) is sequential per stream and runs on the host; feed it the dB
+    frames the GPU computed.  Result fields are properties that copy out of the native state."""
+
+    _FIELDS = {"x_vqt_smoothed": 0, "x_vqt_peakfiltered": 1, "x_vqt_afterglow": 2, "calmness": 3,
+               "pitch_accuracy": 4, "pitch_deviation": 5}
+
+    def __init__(self, range: VqtRange, params: Optional[FullAnalysisParameters] = None):
+        self._L = _lib.load()
+        self.range = range
+        self.params = params or FullAnalysisParameters()
+        self._h = C.c_void_p()
+        cp = self.params._c()
+        _check(self._L.pvq_analysis_state_create(range.min_freq, range.octaves, range.buckets_per_octave, C.byref(cp),
+                                                 C.byref(self._h)))
+        self._n = self._L.pvq_analysis_state_n_buckets(self._h)
+
+    new = classmethod(lambda cls, range, params=None: cls(range, params))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._L.pvq_analysis_state_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def update_vqt_smoothing_duration(self, new_duration: Optional[float]) -> None:
+        """analysis.rs:251; None disables smoothing (EMA pass-through)"""
+        if new_duration is None:
+            _check(self._L.pvq_analysis_state_update_vqt_smoothing_duration(self._h, 0, 0))
+        else:
+            _check(self._L.pvq_analysis_state_update_vqt_smoothing_duration(self._h, 1, int(round(new_duration * 1e9))))
+
+    def preprocess(self, x_vqt, frame_time: float) -> None:
+        """analysis.rs:288; frame_time in seconds"""
+        x = np.ascontiguousarray(x_vqt, np.float32)
+        if x.ndim != 1 or x.size != self._n:
+            raise AssertionError("x_vqt.len() == self.range.n_buckets()")  # analysis.rs:289 asserts
+        _check(self._L.pvq_analysis_state_preprocess(self._h, x.ctypes.data_as(C.POINTER(C.c_float)), x.size,
+                                                     int(round(frame_time * 1e9))))
+
+    def bin_to_frequency(self, bin_idx: int) -> float:
+        return float(self._L.pvq_analysis_state_bin_to_frequency(self._h, bin_idx))
+
+    def _field(self, which: int) -> np.ndarray:
+        out = np.empty(self._n, np.float32)
+        _check(self._L.pvq_analysis_state_get_field(self._h, which, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def __getattr__(self, name):
+        f = AnalysisState._FIELDS.get(name)
+        if f is None:
+            raise AttributeError(name)
+        return self._field(f)
+
+    @property
+    def peaks(self) -> set:
+        buf = np.zeros(max(self._n, 1), np.uint32)
+        k = self._L.pvq_analysis_state_get_peaks(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint32)), buf.size)
+        return set(int(v) for v in buf[:k])
+
+    @property
+    def peaks_continuous(self) -> List[ContinuousPeak]:
+        ce = np.zeros(max(self._n, 1), np.float32)
+        sz = np.zeros(max(self._n, 1), np.float32)
+        k = self._L.pvq_analysis_state_get_peaks_continuous(self._h, ce.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            sz.ctypes.data_as(C.POINTER(C.c_float)), ce.size)
+        return [ContinuousPeak(float(ce[i]), float(sz[i])) for i in range(k)]
+
+    @property
+    def smoothed_scene_calmness(self) -> float:
+        return float(self._L.pvq_analysis_state_scene_calmness(self._h))
+
+    @property
+    def smoothed_tuning_grid_inaccuracy(self) -> float:
+        return float(self._L.pvq_analysis_state_tuning_grid_inaccuracy(self._h))

@@ -17,6 +17,11 @@ EXPORTS = [
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
     "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_blockdft_columns",
+    "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
+    "pvq_analysis_state_update_vqt_smoothing_duration", "pvq_analysis_state_preprocess",
+    "pvq_analysis_state_bin_to_frequency", "pvq_analysis_state_n_buckets", "pvq_analysis_state_get_field",
+    "pvq_analysis_state_get_peaks", "pvq_analysis_state_get_peaks_continuous", "pvq_analysis_state_scene_calmness",
+    "pvq_analysis_state_tuning_grid_inaccuracy",
 ]
 
 PVQ_OK = 0
@@ -52,6 +57,21 @@ class CAnalysisParams(C.Structure):
         ("bass_min_prominence", C.c_float),
         ("bass_min_height", C.c_float),
         ("highest_bassnote", C.c_uint32),
+        ("harmonic_threshold", C.c_float),
+    ]
+
+
+class CAnalysisFullParams(C.Structure):
+    _fields_ = [
+        ("spectrogram_length", C.c_uint32),
+        ("peak_min_prominence", C.c_float), ("peak_min_height", C.c_float),
+        ("bass_min_prominence", C.c_float), ("bass_min_height", C.c_float),
+        ("highest_bassnote", C.c_uint32),
+        ("vqt_smoothing_duration_base_ns", C.c_uint64),
+        ("vqt_smoothing_calmness_min", C.c_float), ("vqt_smoothing_calmness_max", C.c_float),
+        ("note_calmness_smoothing_duration_ns", C.c_uint64),
+        ("scene_calmness_smoothing_duration_ns", C.c_uint64),
+        ("tuning_inaccuracy_smoothing_duration_ns", C.c_uint64),
         ("harmonic_threshold", C.c_float),
     ]
 
@@ -116,5 +136,21 @@ def load():
     L.pvq_vqt_last_kernel_launches.argtypes = [vp, up, C.c_uint32]; L.pvq_vqt_last_kernel_launches.restype = C.c_uint32
     L.pvq_vqt_last_frames_per_launch.argtypes = [vp]; L.pvq_vqt_last_frames_per_launch.restype = C.c_uint32
     L.pvq_vqt_kernel_name.argtypes = [C.c_uint32]; L.pvq_vqt_kernel_name.restype = C.c_char_p
+    afp = C.POINTER(CAnalysisFullParams)
+    L.pvq_analysis_full_default_params.argtypes = [afp]
+    L.pvq_analysis_state_create.argtypes = [C.c_float, C.c_uint32, C.c_uint32, afp, C.POINTER(vp)]
+    L.pvq_analysis_state_create.restype = C.c_int
+    L.pvq_analysis_state_destroy.argtypes = [vp]
+    L.pvq_analysis_state_update_vqt_smoothing_duration.argtypes = [vp, C.c_int, C.c_uint64]
+    L.pvq_analysis_state_update_vqt_smoothing_duration.restype = C.c_int
+    L.pvq_analysis_state_preprocess.argtypes = [vp, fp, C.c_size_t, C.c_uint64]; L.pvq_analysis_state_preprocess.restype = C.c_int
+    L.pvq_analysis_state_bin_to_frequency.argtypes = [vp, C.c_uint32]; L.pvq_analysis_state_bin_to_frequency.restype = C.c_float
+    L.pvq_analysis_state_n_buckets.argtypes = [vp]; L.pvq_analysis_state_n_buckets.restype = C.c_uint32
+    L.pvq_analysis_state_get_field.argtypes = [vp, C.c_int, fp]; L.pvq_analysis_state_get_field.restype = C.c_int
+    L.pvq_analysis_state_get_peaks.argtypes = [vp, up, C.c_uint32]; L.pvq_analysis_state_get_peaks.restype = C.c_uint32
+    L.pvq_analysis_state_get_peaks_continuous.argtypes = [vp, fp, fp, C.c_uint32]
+    L.pvq_analysis_state_get_peaks_continuous.restype = C.c_uint32
+    L.pvq_analysis_state_scene_calmness.argtypes = [vp]; L.pvq_analysis_state_scene_calmness.restype = C.c_float
+    L.pvq_analysis_state_tuning_grid_inaccuracy.argtypes = [vp]; L.pvq_analysis_state_tuning_grid_inaccuracy.restype = C.c_float
     _lib = L
     return L

@@ -3,10 +3,14 @@
 #include <memory>
 
 #include "../../include/pvq.h"
+#include "analysis_host.hpp"
 #include "vqt_engine.hpp"
 
 struct pvq_vqt {
     std::unique_ptr<pvq::Vqt> impl;
+};
+struct pvq_analysis_state {
+    std::unique_ptr<pvq::AnalysisState> impl;
 };
 
 namespace {
@@ -231,6 +235,116 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt* v, const float* d_pcm, size_t n
     return v->impl->vqt_analyze_batch_device(d_pcm, n_lead, hop, n_frames, to_cpp(a), d_out_db, d_peak_mask,
                                              d_peak_count, d_center, d_size, max_peaks,
                                              static_cast<hipStream_t>(stream));
+}
+
+void pvq_analysis_full_default_params(pvq_analysis_full_params* p) {
+    if (!p) return;
+    const pvq::FullAnalysisParameters d;
+    p->spectrogram_length = d.spectrogram_length;
+    p->peak_min_prominence = d.peak_config.min_prominence;
+    p->peak_min_height = d.peak_config.min_height;
+    p->bass_min_prominence = d.bassline_peak_config.min_prominence;
+    p->bass_min_height = d.bassline_peak_config.min_height;
+    p->highest_bassnote = d.highest_bassnote;
+    p->vqt_smoothing_duration_base_ns = d.vqt_smoothing_duration_base.ns;
+    p->vqt_smoothing_calmness_min = d.vqt_smoothing_calmness_min;
+    p->vqt_smoothing_calmness_max = d.vqt_smoothing_calmness_max;
+    p->note_calmness_smoothing_duration_ns = d.note_calmness_smoothing_duration.ns;
+    p->scene_calmness_smoothing_duration_ns = d.scene_calmness_smoothing_duration.ns;
+    p->tuning_inaccuracy_smoothing_duration_ns = d.tuning_inaccuracy_smoothing_duration.ns;
+    p->harmonic_threshold = d.harmonic_threshold;
+}
+
+pvq_status pvq_analysis_state_create(float min_freq, uint32_t octaves, uint32_t buckets_per_octave,
+                                     const pvq_analysis_full_params* params, pvq_analysis_state** out) {
+    if (!out) return null_handle();
+    *out = nullptr;
+    if (!(min_freq > 0.0f) || octaves == 0 || buckets_per_octave == 0) {
+        pvq::set_last_error("invalid VqtRange");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    pvq::FullAnalysisParameters q;
+    if (params) {
+        q.spectrogram_length = params->spectrogram_length;
+        q.peak_config = {params->peak_min_prominence, params->peak_min_height};
+        q.bassline_peak_config = {params->bass_min_prominence, params->bass_min_height};
+        q.highest_bassnote = params->highest_bassnote;
+        q.vqt_smoothing_duration_base = pvq::Duration{params->vqt_smoothing_duration_base_ns};
+        q.vqt_smoothing_calmness_min = params->vqt_smoothing_calmness_min;
+        q.vqt_smoothing_calmness_max = params->vqt_smoothing_calmness_max;
+        q.note_calmness_smoothing_duration = pvq::Duration{params->note_calmness_smoothing_duration_ns};
+        q.scene_calmness_smoothing_duration = pvq::Duration{params->scene_calmness_smoothing_duration_ns};
+        q.tuning_inaccuracy_smoothing_duration = pvq::Duration{params->tuning_inaccuracy_smoothing_duration_ns};
+        q.harmonic_threshold = params->harmonic_threshold;
+    }
+    pvq::VqtRange r;
+    r.min_freq = min_freq;
+    r.octaves = octaves;
+    r.buckets_per_octave = buckets_per_octave;
+    *out = new pvq_analysis_state{std::unique_ptr<pvq::AnalysisState>(new pvq::AnalysisState(r, q))};
+    return PVQ_OK;
+}
+
+void pvq_analysis_state_destroy(pvq_analysis_state* s) { delete s; }
+
+pvq_status pvq_analysis_state_update_vqt_smoothing_duration(pvq_analysis_state* s, int has_duration, uint64_t duration_ns) {
+    if (!s) return null_handle();
+    s->impl->update_vqt_smoothing_duration(has_duration != 0, pvq::Duration{duration_ns});
+    return PVQ_OK;
+}
+
+pvq_status pvq_analysis_state_preprocess(pvq_analysis_state* s, const float* x_vqt, size_t len, uint64_t frame_time_ns) {
+    if (!s || !x_vqt) return null_handle();
+    if (!s->impl->preprocess(x_vqt, len, pvq::Duration{frame_time_ns})) {
+        pvq::set_last_error("x_vqt.len() == range.n_buckets()");
+        return PVQ_ERR_BAD_LENGTH;
+    }
+    return PVQ_OK;
+}
+
+float pvq_analysis_state_bin_to_frequency(const pvq_analysis_state* s, uint32_t bin) {
+    return s ? s->impl->bin_to_frequency(bin) : 0.0f;
+}
+uint32_t pvq_analysis_state_n_buckets(const pvq_analysis_state* s) { return s ? s->impl->range.n_buckets() : 0; }
+
+pvq_status pvq_analysis_state_get_field(const pvq_analysis_state* s, pvq_analysis_field f, float* out) {
+    if (!s || !out) return null_handle();
+    const pvq::AnalysisState& a = *s->impl;
+    const uint32_t n = a.range.n_buckets();
+    switch (f) {
+        case PVQ_FIELD_X_VQT_SMOOTHED:
+            for (uint32_t i = 0; i < n; ++i) out[i] = a.x_vqt_smoothed[i].get();
+            return PVQ_OK;
+        case PVQ_FIELD_X_VQT_PEAKFILTERED: std::memcpy(out, a.x_vqt_peakfiltered.data(), n * sizeof(float)); return PVQ_OK;
+        case PVQ_FIELD_X_VQT_AFTERGLOW: std::memcpy(out, a.x_vqt_afterglow.data(), n * sizeof(float)); return PVQ_OK;
+        case PVQ_FIELD_CALMNESS:
+            for (uint32_t i = 0; i < n; ++i) out[i] = a.calmness[i].get();
+            return PVQ_OK;
+        case PVQ_FIELD_PITCH_ACCURACY: std::memcpy(out, a.pitch_accuracy.data(), n * sizeof(float)); return PVQ_OK;
+        case PVQ_FIELD_PITCH_DEVIATION: std::memcpy(out, a.pitch_deviation.data(), n * sizeof(float)); return PVQ_OK;
+    }
+    pvq::set_last_error("unknown field");
+    return PVQ_ERR_INVALID_ARG;
+}
+
+uint32_t pvq_analysis_state_get_peaks(const pvq_analysis_state* s, uint32_t* out, uint32_t capacity) {
+    if (!s) return 0;
+    const auto& p = s->impl->peaks;
+    for (uint32_t i = 0; i < p.size() && i < capacity && out; ++i) out[i] = p[i];
+    return static_cast<uint32_t>(p.size());
+}
+uint32_t pvq_analysis_state_get_peaks_continuous(const pvq_analysis_state* s, float* center, float* size, uint32_t capacity) {
+    if (!s) return 0;
+    const auto& p = s->impl->peaks_continuous;
+    for (uint32_t i = 0; i < p.size() && i < capacity; ++i) {
+        if (center) center[i] = p[i].center;
+        if (size) size[i] = p[i].size;
+    }
+    return static_cast<uint32_t>(p.size());
+}
+float pvq_analysis_state_scene_calmness(const pvq_analysis_state* s) { return s ? s->impl->smoothed_scene_calmness.get() : 0.0f; }
+float pvq_analysis_state_tuning_grid_inaccuracy(const pvq_analysis_state* s) {
+    return s ? s->impl->smoothed_tuning_grid_inaccuracy.get() : 0.0f;
 }
 
 pvq_status pvq_vqt_set_profiling(pvq_vqt* v, int enable) {
