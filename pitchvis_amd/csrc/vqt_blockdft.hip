@@ -368,6 +368,140 @@ __global__ __launch_bounds__(256) void blockdft_gemm_bf16x3(GemmBfArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused form (windows of <= 64 hop blocks): the 128 x 32-complex-column tile of P never leaves the
+// workgroup.  After the K loop the accumulators go to LDS (aliasing the staging buffers), the doubling
+// tree runs there, and only X_f for the tile's 128 - Nb + 1 complete frames is written.  Row tiles of a
+// group therefore advance by S_g = 129 - Nb_g blocks (1.02x ... 1.97x recomputation of the GEMM rows,
+// +20 % MFMA work at 48 kHz / hop 256) in exchange for dropping the P round trip through memory
+// (172 MB written + ~200 MB read per 32 768 frames) and the separate combine launch.
+// ------------------------------------------------------------------------------------------------
+struct GemmTreeArgs {
+    const float* pcm_base;
+    unsigned pcm_bytes;
+    const float* E;
+    int ld;                   // Ntot
+    float2* X;                // [n_frames][xc]
+    int xc;
+    int n_frames;             // frames of this launch
+    int K;                    // hop
+    long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
+    int n_groups;
+    int blk_off[9];           // first block of each group (blocks of group g: n_tiles_g * mt8_g)
+    const BlockGroup* groups;
+    const float2* comb_tw;
+};
+
+constexpr int FT_BM = 128, FT_BN = 64, FT_BK = 16;
+
+__global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[FT_BM * FT_BN];  // 32 KB: staging buffers, then the P tile
+    float (*As)[FT_BM][FT_BK + 1] = reinterpret_cast<float (*)[FT_BM][FT_BK + 1]>(smem);                       // [2][128][17]
+    float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * FT_BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int g = 0;
+    while (g + 1 < a.n_groups && (int)blockIdx.x >= a.blk_off[g + 1]) ++g;
+    const BlockGroup G = a.groups[g];
+    const int S = FT_BM - G.nb + 1;                     // complete frames per row tile
+    const int r = blockIdx.x - a.blk_off[g];
+    const int xcd = r & 7, bi = r >> 3;                 // XCD-aware: an XCD owns whole row panels
+    const int ntl = bi % G.n_tiles;
+    const int mt = (bi / G.n_tiles) * 8 + xcd;
+    const int f0 = mt * S;                              // first frame == first block row of this tile
+    if (f0 >= a.n_frames) return;
+    const int nt = G.tile0 + ntl;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long s = a.base + G.s_rel;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+
+    constexpr int A_PER = FT_BM * FT_BK / 256;          // 8
+    constexpr int A_ROWS_PER_PASS = 256 / FT_BK;        // 16
+    float ra[A_PER];
+    float4 rb;
+    const int a_row = tid / FT_BK, a_col = tid % FT_BK;
+    const int b_row = (tid * 4) / FT_BN, b_col = (tid * 4) % FT_BN;
+    const unsigned a_off0 = (unsigned)((s + (long long)(f0 + a_row) * a.K + a_col) * 4ll);
+    const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
+    const float* e_ptr = a.E + (size_t)b_row * a.ld + (size_t)nt * FT_BN + b_col;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc0[q] = 0.0f;
+        acc1[q] = 0.0f;
+    }
+#define PVQ_FT_LOAD(k0)                                                                                          \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) ra[i] = __builtin_bit_cast(                            \
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
+        rb = *reinterpret_cast<const float4*>(e_ptr + (size_t)(k0) * a.ld);                                      \
+    }
+#define PVQ_FT_STORE(buf)                                                                                        \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) As[buf][a_row + i * A_ROWS_PER_PASS][a_col] = ra[i];   \
+        *reinterpret_cast<float4*>(&Bs[buf][b_row][b_col]) = rb;                                                 \
+    }
+    const int n_iter = a.K / FT_BK;
+    PVQ_FT_LOAD(0);
+    PVQ_FT_STORE(0);
+    __syncthreads();
+    const int ar = wm * 64 + (lane & 31), kh = lane >> 5, bc = wn * 32 + (lane & 31);
+    for (int it = 0; it < n_iter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_iter) PVQ_FT_LOAD((it + 1) * FT_BK);
+#pragma unroll
+        for (int kk = 0; kk < FT_BK / 2; ++kk) {
+            const float a0 = As[buf][ar][2 * kk + kh];
+            const float a1 = As[buf][ar + 32][2 * kk + kh];
+            const float b = Bs[buf][2 * kk + kh][bc];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+        }
+        if (it + 1 < n_iter) PVQ_FT_STORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef PVQ_FT_LOAD
+#undef PVQ_FT_STORE
+    // P tile -> LDS as [row][64 floats] = [row][32 complex]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = wm * 64 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        smem[row * FT_BN + bc] = acc0[q];
+        smem[(row + 32) * FT_BN + bc] = acc1[q];
+    }
+    __syncthreads();
+    float2 (*A)[CB_C] = reinterpret_cast<float2 (*)[CB_C]>(smem);  // [128][32]
+    const int c = tid & (CB_C - 1);
+    constexpr int PER = FT_BM * CB_C / 256;  // 16
+    int valid = FT_BM;
+    for (int l = 0; l < G.levels; ++l) {
+        const int st = 1 << l;
+        valid -= st;
+        const float2 w = a.comb_tw[G.tw_off + l * (G.n_tiles * CB_C) + ntl * CB_C + c];
+        float2 v[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int j = (tid + t * 256) / CB_C;
+            if (j < valid) {
+                const float2 lo = A[j][c], hi = A[j + st][c];
+                v[t] = make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int j = (tid + t * 256) / CB_C;
+            if (j < valid) A[j][c] = v[t];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < S * CB_C; idx += 256) {
+        const int j = idx / CB_C;
+        const int f = f0 + j;
+        if (f < a.n_frames) a.X[(size_t)f * a.xc + nt * CB_C + c] = A[j][c];
+    }
+}
+
 struct GemmVariant {
     int bm, bn;
     void (*kernel)(GemmArgs);
@@ -856,50 +990,79 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         ga.n_col_tiles = t->n_tiles * GM_BN / gv.bn;
         ga.p_rows = (int)rows_cap;
         const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
-        if (overlap && c >= 2) PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_comb[b], 0));  // combine(c-2) is done with P[b]
-        slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
-        if (use_bf) {
-            GemmBfArgs gb;
-            gb.pcm_base = ga.pcm_base;
-            gb.pcm_bytes = ga.pcm_bytes;
-            gb.Et = t->d_Et;
-            gb.ntot = ntot;
-            gb.P = P;
-            gb.n_rows = n_rows;
-            gb.K = (int)hop;
-            gb.tile_s = t->d_tile_s;
-            gb.base = ga.base;
-            gb.n_col_tiles = t->n_tiles;
-            gb.p_rows = (int)rows_cap;
-            const int mt8 = (((n_rows + BF_BM - 1) / BF_BM) + 7) / 8 * 8;
-            hipLaunchKernelGGL(blockdft_gemm_bf16x3, dim3(gb.n_col_tiles * mt8), dim3(256), 0, s_gemm, gb);
+        static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
+        const bool fused = fuse_env && !use_bf && !overlap && t->nb_max <= 64 && t->n_groups <= 8 && hop % FT_BK == 0;
+        if (fused) {
+            GemmTreeArgs fa;
+            fa.pcm_base = ga.pcm_base;
+            fa.pcm_bytes = ga.pcm_bytes;
+            fa.E = t->d_E;
+            fa.ld = ntot;
+            fa.X = X;
+            fa.xc = xc;
+            fa.n_frames = (int)nf;
+            fa.K = (int)hop;
+            fa.base = ga.base;
+            fa.n_groups = t->n_groups;
+            int off = 0;
+            for (int g = 0; g < t->n_groups; ++g) {
+                fa.blk_off[g] = off;
+                const int S = FT_BM - t->groups[g].nb + 1;
+                const int mt8 = ((((int)nf + S - 1) / S) + 7) / 8 * 8;
+                off += t->groups[g].n_tiles * mt8;
+            }
+            for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
+            fa.groups = t->d_groups;
+            fa.comb_tw = t->d_comb_tw;
+            slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
+            hipLaunchKernelGGL(blockdft_gemm_tree, dim3(off), dim3(256), 0, s_gemm, fa);
+            slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
         } else {
-            hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, s_gemm, ga);
+            if (overlap && c >= 2) PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_comb[b], 0));  // combine(c-2) is done with P[b]
+            slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
+            if (use_bf) {
+                GemmBfArgs gb;
+                gb.pcm_base = ga.pcm_base;
+                gb.pcm_bytes = ga.pcm_bytes;
+                gb.Et = t->d_Et;
+                gb.ntot = ntot;
+                gb.P = P;
+                gb.n_rows = n_rows;
+                gb.K = (int)hop;
+                gb.tile_s = t->d_tile_s;
+                gb.base = ga.base;
+                gb.n_col_tiles = t->n_tiles;
+                gb.p_rows = (int)rows_cap;
+                const int mt8 = (((n_rows + BF_BM - 1) / BF_BM) + 7) / 8 * 8;
+                hipLaunchKernelGGL(blockdft_gemm_bf16x3, dim3(gb.n_col_tiles * mt8), dim3(256), 0, s_gemm, gb);
+            } else {
+                hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, s_gemm, ga);
+            }
+            slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
+            if (overlap) {
+                PVQ_HIP(hipEventRecord(t->ev_gemm[b], s_gemm));
+                PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_gemm[b], 0));
+            }
+            CombineArgs ca;
+            ca.P = P;
+            ca.p_rows = (int)rows_cap;
+            ca.X = X;
+            ca.xc = xc;
+            ca.n_frames = (int)nf;
+            ca.n_rows = n_rows;
+            ca.tile_group = t->d_tile_group;
+            ca.groups = t->d_groups;
+            ca.comb_tw = t->d_comb_tw;
+            slot_begin(SLOT_BLOCKDFT_COMBINE, s_post);
+            if (t->nb_max <= 64)
+                hipLaunchKernelGGL((blockdft_combine<128, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 127) / 128)), dim3(256), 0,
+                                   s_post, ca);
+            else
+                hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 256>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256),
+                                   0, s_post, ca);
+            slot_end(SLOT_BLOCKDFT_COMBINE, s_post);
+            if (overlap) PVQ_HIP(hipEventRecord(t->ev_comb[b], s_post));
         }
-        slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
-        if (overlap) {
-            PVQ_HIP(hipEventRecord(t->ev_gemm[b], s_gemm));
-            PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_gemm[b], 0));
-        }
-        CombineArgs ca;
-        ca.P = P;
-        ca.p_rows = (int)rows_cap;
-        ca.X = X;
-        ca.xc = xc;
-        ca.n_frames = (int)nf;
-        ca.n_rows = n_rows;
-        ca.tile_group = t->d_tile_group;
-        ca.groups = t->d_groups;
-        ca.comb_tw = t->d_comb_tw;
-        slot_begin(SLOT_BLOCKDFT_COMBINE, s_post);
-        if (t->nb_max <= 64)
-            hipLaunchKernelGGL((blockdft_combine<128, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 127) / 128)), dim3(256), 0,
-                               s_post, ca);
-        else
-            hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 256>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256),
-                               0, s_post, ca);
-        slot_end(SLOT_BLOCKDFT_COMBINE, s_post);
-        if (overlap) PVQ_HIP(hipEventRecord(t->ev_comb[b], s_post));
         DotsArgs da;
         da.X = X;
         da.xc = xc;
