@@ -115,6 +115,11 @@ void free_blockdft_tables(BlockDftTables* t) {
 // GEMM: P[j][n] = sum_m pcm[s(n) + j*K + m] * E[m][n]        (exact fp32 MFMA)
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// 16-byte raw buffer load.  Bound to the LLVM intrinsic by name: this compiler lowers
+// __builtin_amdgcn_raw_buffer_load_b64 / _b128 to a single-dword load.
+__device__ f32x4 pvq_raw_buffer_load_f32x4(i32x4 srsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 struct GemmArgs {
     const float* pcm_base;    // rebased per launch so that byte offsets fit 32 bits
@@ -390,26 +395,78 @@ struct GemmTreeArgs {
     int blk_off[9];           // first block of each group (blocks of group g: n_tiles_g * mt8_g)
     const BlockGroup* groups;
     const float2* comb_tw;
+    const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
+    int dbg;
 };
 
 constexpr int FT_BM = 128, FT_BN = 64, FT_BK = 16;
+
+// which (group, row tile, column tile) a workgroup of the fused kernels owns
+struct FusedTile {
+    BlockGroup G;
+    int S;        // complete frames per row tile
+    int ntl, nt;  // column tile within the group / global
+    int f0;       // first frame == first block row
+};
+__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
+    FusedTile t;
+    int g = 0;
+    while (g + 1 < a.n_groups && (int)blockIdx.x >= a.blk_off[g + 1]) ++g;
+    t.G = a.groups[g];
+    t.S = FT_BM - t.G.nb + 1;
+    const int r = blockIdx.x - a.blk_off[g];
+    const int xcd = r & 7, bi = r >> 3;                 // XCD-aware: an XCD owns whole row panels
+    t.ntl = bi % t.G.n_tiles;
+    t.f0 = ((bi / t.G.n_tiles) * 8 + xcd) * t.S;
+    t.nt = t.G.tile0 + t.ntl;
+    return t;
+}
+
+// doubling tree over the [128][32 complex] P tile in LDS, then the store of the S complete frames
+__device__ __forceinline__ void fused_tree_store(float* smem, const FusedTile& t, const GemmTreeArgs& a, int tid) {
+    float2 (*A)[CB_C] = reinterpret_cast<float2 (*)[CB_C]>(smem);  // [128][32]
+    const int c = tid & (CB_C - 1);
+    constexpr int PER = FT_BM * CB_C / 256;  // 16
+    int valid = FT_BM;
+    const int levels = (a.dbg & 2) ? 0 : t.G.levels;
+    for (int l = 0; l < levels; ++l) {
+        const int st = 1 << l;
+        valid -= st;
+        const float2 w = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
+        float2 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = (tid + q * 256) / CB_C;
+            if (j < valid) {
+                const float2 lo = A[j][c], hi = A[j + st][c];
+                v[q] = make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = (tid + q * 256) / CB_C;
+            if (j < valid) A[j][c] = v[q];
+        }
+        __syncthreads();
+    }
+    if (a.dbg & 4) return;
+    for (int idx = tid; idx < t.S * CB_C; idx += 256) {
+        const int j = idx / CB_C;
+        const int f = t.f0 + j;
+        if (f < a.n_frames) a.X[(size_t)f * a.xc + t.nt * CB_C + c] = A[j][c];
+    }
+}
 
 __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FT_BM * FT_BN];  // 32 KB: staging buffers, then the P tile
     float (*As)[FT_BM][FT_BK + 1] = reinterpret_cast<float (*)[FT_BM][FT_BK + 1]>(smem);                       // [2][128][17]
     float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * FT_BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int g = 0;
-    while (g + 1 < a.n_groups && (int)blockIdx.x >= a.blk_off[g + 1]) ++g;
-    const BlockGroup G = a.groups[g];
-    const int S = FT_BM - G.nb + 1;                     // complete frames per row tile
-    const int r = blockIdx.x - a.blk_off[g];
-    const int xcd = r & 7, bi = r >> 3;                 // XCD-aware: an XCD owns whole row panels
-    const int ntl = bi % G.n_tiles;
-    const int mt = (bi / G.n_tiles) * 8 + xcd;
-    const int f0 = mt * S;                              // first frame == first block row of this tile
+    const FusedTile T = fused_tile(a);
+    const BlockGroup& G = T.G;
+    const int f0 = T.f0, nt = T.nt;
     if (f0 >= a.n_frames) return;
-    const int nt = G.tile0 + ntl;
     const int wm = wave >> 1, wn = wave & 1;
     const long long s = a.base + G.s_rel;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
@@ -470,36 +527,138 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
         smem[(row + 32) * FT_BN + bc] = acc1[q];
     }
     __syncthreads();
-    float2 (*A)[CB_C] = reinterpret_cast<float2 (*)[CB_C]>(smem);  // [128][32]
-    const int c = tid & (CB_C - 1);
-    constexpr int PER = FT_BM * CB_C / 256;  // 16
-    int valid = FT_BM;
-    for (int l = 0; l < G.levels; ++l) {
-        const int st = 1 << l;
-        valid -= st;
-        const float2 w = a.comb_tw[G.tw_off + l * (G.n_tiles * CB_C) + ntl * CB_C + c];
-        float2 v[PER];
+    fused_tree_store(smem, T, a, tid);
+}
+
+// Split-bf16 form of the fused kernel: same tile, same epilogue; the K loop multiplies hi/mid/lo bf16
+// planes (six v_mfma_f32_32x32x16_bf16 per fp32 product block, see blockdft_gemm_bf16x3).  The PCM tile
+// is split while it is staged (16 consecutive samples per thread: b128 loads, b128 LDS writes); E comes
+// pre-split.  LDS: 3 x (128 + 64) rows x 40 bf16 = 45 KB of staging, aliased by the 32 KB P tile.
+constexpr int FB_BK = 32, FB_LD = FB_BK + 8;
+constexpr int FB_LDS_BYTES = 3 * (FT_BM + FT_BN) * FB_LD * 2;
+
+// K loop of the split-bf16 fused kernel.  VEC: the tile's samples all lie inside the stream, so each
+// thread's 16 consecutive samples come as four 16-byte loads; otherwise (tiles that touch the stream start
+// or end) as 16 dword loads, each range-checked by the buffer hardware.
+template <bool VEC>
+__device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsigned char* smem_raw, unsigned a_off0, const __bf16* e_ptr,
+                                                   int tid, f32x16& acc0, f32x16& acc1) {
+    __bf16 (*As)[FT_BM][FB_LD] = reinterpret_cast<__bf16 (*)[FT_BM][FB_LD]>(smem_raw);
+    __bf16 (*Bs)[FT_BN][FB_LD] = reinterpret_cast<__bf16 (*)[FT_BN][FB_LD]>(smem_raw + 3 * FT_BM * FB_LD * 2);
+    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+    // A staging: thread -> (row = tid / 2, 16 consecutive k); B staging: thread -> (n = tid / 4, 8 consecutive k) x 3 planes
+    const int a_row = tid >> 1, a_k = (tid & 1) * 16;
+    const int b_n = tid >> 2, b_c = (tid & 3) * 8;
+    const size_t plane = (size_t)a.ld * a.K;
+    float ra[16];
+    bf16x8 rb[3];
+    auto load = [&](int k0) {
+        if (VEC) {
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int j = (tid + t * 256) / CB_C;
-            if (j < valid) {
-                const float2 lo = A[j][c], hi = A[j + st][c];
-                v[t] = make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)(a_off0 + (unsigned)k0 * 4u + 16u * q), 0, 0);
+                ra[4 * q + 0] = v[0];
+                ra[4 * q + 1] = v[1];
+                ra[4 * q + 2] = v[2];
+                ra[4 * q + 3] = v[3];
             }
-        }
-        __syncthreads();
+        } else {
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int j = (tid + t * 256) / CB_C;
-            if (j < valid) A[j][c] = v[t];
+            for (int q = 0; q < 16; ++q)
+                ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)k0 * 4u + 4u * q, 0, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const bf16x8*>(e_ptr + p * plane + k0);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 vh, vm, vl;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float x = ra[8 * h + q];
+                const __bf16 hi = (__bf16)x;
+                const float r1 = x - (float)hi;
+                const __bf16 mid = (__bf16)r1;
+                vh[q] = hi;
+                vm[q] = mid;
+                vl[q] = (__bf16)(r1 - (float)mid);
+            }
+            *reinterpret_cast<bf16x8*>(&As[0][a_row][a_k + 8 * h]) = vh;
+            *reinterpret_cast<bf16x8*>(&As[1][a_row][a_k + 8 * h]) = vm;
+            *reinterpret_cast<bf16x8*>(&As[2][a_row][a_k + 8 * h]) = vl;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(&Bs[p][b_n][b_c]) = rb[p];
+    };
+    const int n_iter = (a.dbg & 1) ? 0 : a.K / FB_BK;
+    const int ar = wm * 64 + (lane & 31), kh = (lane >> 5) * 8, bc = wn * 32 + (lane & 31);
+    load(0);
+    for (int it = 0; it < n_iter; ++it) {
+        store();
+        __syncthreads();
+        if (it + 1 < n_iter) load((it + 1) * FB_BK);
+#pragma unroll
+        for (int kk = 0; kk < FB_BK / 16; ++kk) {
+            bf16x8 a0[3], a1[3], bv[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a0[p] = *reinterpret_cast<const bf16x8*>(&As[p][ar][kk * 16 + kh]);
+                a1[p] = *reinterpret_cast<const bf16x8*>(&As[p][ar + 32][kk * 16 + kh]);
+                bv[p] = *reinterpret_cast<const bf16x8*>(&Bs[p][bc][kk * 16 + kh]);
+            }
+            // smallest terms first
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], bv[1], acc0, 0, 0, 0);  // mid*mid
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], bv[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], bv[2], acc0, 0, 0, 0);  // hi*lo
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], bv[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[2], bv[0], acc0, 0, 0, 0);  // lo*hi
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[2], bv[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], bv[1], acc0, 0, 0, 0);  // hi*mid
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], bv[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], bv[0], acc0, 0, 0, 0);  // mid*hi
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], bv[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], bv[0], acc0, 0, 0, 0);  // hi*hi
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], bv[0], acc1, 0, 0, 0);
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < S * CB_C; idx += 256) {
-        const int j = idx / CB_C;
-        const int f = f0 + j;
-        if (f < a.n_frames) a.X[(size_t)f * a.xc + nt * CB_C + c] = A[j][c];
+}
+
+__global__ __launch_bounds__(256) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[FB_LDS_BYTES];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FusedTile T = fused_tile(a);
+    const int f0 = T.f0, nt = T.nt;
+    if (f0 >= a.n_frames) return;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long s = a.base + T.G.s_rel;
+    const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)FT_BM * a.K;  // sample range of the tile
+    const unsigned a_off0 = (unsigned)((tile_lo + (long long)(tid >> 1) * a.K + (tid & 1) * 16) * 4ll);
+    const __bf16* e_ptr = a.Et + (size_t)(nt * FT_BN + (tid >> 2)) * a.K + (tid & 3) * 8;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc0[q] = 0.0f;
+        acc1[q] = 0.0f;
     }
+    if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
+        fused_bf16x3_kloop<true>(a, smem_raw, a_off0, e_ptr, tid, acc0, acc1);
+    else
+        fused_bf16x3_kloop<false>(a, smem_raw, a_off0, e_ptr, tid, acc0, acc1);
+    const int bc = wn * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = wm * 64 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        smem[row * FT_BN + bc] = acc0[q];
+        smem[(row + 32) * FT_BN + bc] = acc1[q];
+    }
+    __syncthreads();
+    fused_tree_store(smem, T, a, tid);
 }
 
 struct GemmVariant {
@@ -991,7 +1150,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         ga.p_rows = (int)rows_cap;
         const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
         static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
-        const bool fused = fuse_env && !use_bf && !overlap && t->nb_max <= 64 && t->n_groups <= 8 && hop % FT_BK == 0;
+        const bool fused = fuse_env && !overlap && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : FT_BK) == 0;
         if (fused) {
             GemmTreeArgs fa;
             fa.pcm_base = ga.pcm_base;
@@ -1014,8 +1173,14 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
+            fa.Et = t->d_Et;
+            fa.dbg = getenv("PVQ_DBG") ? atoi(getenv("PVQ_DBG")) : 0;
             slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
-            hipLaunchKernelGGL(blockdft_gemm_tree, dim3(off), dim3(256), 0, s_gemm, fa);
+            if (use_bf) {
+                hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3, dim3(off), dim3(256), 0, s_gemm, fa);
+            } else {
+                hipLaunchKernelGGL(blockdft_gemm_tree, dim3(off), dim3(256), 0, s_gemm, fa);
+            }
             slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
         } else {
             if (overlap && c >= 2) PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_comb[b], 0));  // combine(c-2) is done with P[b]

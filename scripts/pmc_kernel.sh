@@ -1,0 +1,32 @@
+#!/bin/bash
+# Developer tool (GPU box): SQ counters of the block-DFT kernels.  usage: scripts/pmc_kernel.sh <tag> <gemm_precision>
+TAG=${1:-pmc}
+PREC=${2:-0}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM" \
+           "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_ACTIVE_INST_SCA"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $ROOT/scripts/dev_time.py 2 $PREC once > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+done
+cd $ROOT
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/$TAG/p*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "pvq::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("gpurun_out/$TAG/summary.txt", "w") as out:
+    for k, d in acc.items():
+        out.write(k + "\n")
+        for c, v in sorted(d.items()):
+            out.write(f"    {c:28s} {sum(v)/len(v):16.0f}  (n={len(v)})\n")
+print(open("gpurun_out/$TAG/summary.txt").read())
+PY
