@@ -56,12 +56,24 @@ struct BlockGroup {
     long long s_rel;  // window begin relative to the end of the n_fft buffer: w0 - n_fft
 };
 
+// 16 output bins (rows of one window group's kernel) and the contiguous range of X columns they read
+struct BandBlock {
+    int x0;      // first X column
+    int kb;      // columns walked (multiple of BD_KU; coefficients beyond the true range are zero)
+    int boff;    // first column of this block in d_band_B (units of 64 floats)
+    int bin0;    // first output bin
+    int nrows;   // 1..16
+};
+constexpr int BD_RB = 16;   // bins per block: 32 MFMA columns = 16 x (re, im)
+constexpr int BD_KU = 4;    // columns per software-pipeline stage
+constexpr int BD_NS = 4;    // pipeline stages
+constexpr int X_PAD_COLS = BD_NS * BD_KU;   // zeroed columns after the last X column (prefetch runs past a block's range)
+
 struct BlockDftTables {
     size_t hop = 0;
     int n_groups = 0;
     int n_tiles = 0;   // total column tiles; Ntot = n_tiles*64 floats, XC = n_tiles*32 complex
     int nb_max = 0;
-    int ell_len = 0;   // max entries per output row
     int n_bins_pad = 0;
     std::vector<BlockGroup> groups;
     std::vector<float> h_E;        // host copy of E
@@ -71,16 +83,14 @@ struct BlockDftTables {
     long long* d_tile_s = nullptr; // [n_tiles] window begin of the tile's group relative to the buffer end
     BlockGroup* d_groups = nullptr;
     float2* d_comb_tw = nullptr;
-    float2* d_ell_val = nullptr;   // [ell_len][n_bins_pad]
-    uint16_t* d_ell_col = nullptr; // X column | 0x8000 (conj)
-    uint16_t* d_row_len = nullptr; // [n_bins_pad]
-    uint16_t* d_row_bin = nullptr; // [n_bins_pad] permuted slot -> bin
+    // banded kernel product: blocks of 16 output bins x their union of spectrum columns, as MFMA B operands
+    struct BandBlock* d_band = nullptr;
+    float* d_band_B = nullptr;     // per block and column: 64 floats in v_mfma_f32_32x32x2_f32 B-operand lane order
+    int* d_band_list = nullptr;    // [4][band_per_wave]: the blocks each wave of a workgroup walks
+    int band_per_wave = 0;
+    int band_cnt[4] = {0, 0, 0, 0};
     float* d_P = nullptr;  size_t p_cap = 0;   // workspace
     float2* d_X = nullptr; size_t x_cap = 0;
-    // two internal streams so that the MFMA GEMM of sub-batch c+1 overlaps the memory-bound stages of c
-    bool streams_ready = false;
-    hipStream_t s_gemm = nullptr, s_post = nullptr;
-    hipEvent_t ev_gemm[2] = {}, ev_comb[2] = {}, ev_fork = nullptr, ev_join_g = nullptr, ev_join_p = nullptr;
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -91,23 +101,11 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_tile_s) (void)hipFree(t->d_tile_s);
     if (t->d_groups) (void)hipFree(t->d_groups);
     if (t->d_comb_tw) (void)hipFree(t->d_comb_tw);
-    if (t->d_ell_val) (void)hipFree(t->d_ell_val);
-    if (t->d_ell_col) (void)hipFree(t->d_ell_col);
-    if (t->d_row_len) (void)hipFree(t->d_row_len);
-    if (t->d_row_bin) (void)hipFree(t->d_row_bin);
+    if (t->d_band) (void)hipFree(t->d_band);
+    if (t->d_band_B) (void)hipFree(t->d_band_B);
+    if (t->d_band_list) (void)hipFree(t->d_band_list);
     if (t->d_P) (void)hipFree(t->d_P);
     if (t->d_X) (void)hipFree(t->d_X);
-    if (t->streams_ready) {
-        (void)hipStreamDestroy(t->s_gemm);
-        (void)hipStreamDestroy(t->s_post);
-        for (int i = 0; i < 2; ++i) {
-            (void)hipEventDestroy(t->ev_gemm[i]);
-            (void)hipEventDestroy(t->ev_comb[i]);
-        }
-        (void)hipEventDestroy(t->ev_fork);
-        (void)hipEventDestroy(t->ev_join_g);
-        (void)hipEventDestroy(t->ev_join_p);
-    }
     delete t;
 }
 
@@ -386,8 +384,8 @@ struct GemmTreeArgs {
     unsigned pcm_bytes;
     const float* E;
     int ld;                   // Ntot
-    float2* X;                // [n_frames][xc]
-    int xc;
+    float2* X;                // column-major: X[col * ldf + frame]
+    int ldf;
     int n_frames;             // frames of this launch
     int K;                    // hop
     long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
@@ -396,7 +394,6 @@ struct GemmTreeArgs {
     const BlockGroup* groups;
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
-    int dbg;
 };
 
 constexpr int FT_BM = 128, FT_BN = 64, FT_BK = 16;
@@ -422,14 +419,16 @@ __device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
     return t;
 }
 
-// doubling tree over the [128][32 complex] P tile in LDS, then the store of the S complete frames
+// doubling tree over the [128][32 complex] P tile in LDS (rows padded to 33 so that the transposed store
+// below is bank-conflict free), then the store of the S complete frames, column-major
+constexpr int FT_LDP = CB_C + 1;                      // P tile row stride in complex elements
+constexpr int FT_P_FLOATS = FT_BM * FT_LDP * 2;       // 33 792 B
 __device__ __forceinline__ void fused_tree_store(float* smem, const FusedTile& t, const GemmTreeArgs& a, int tid) {
-    float2 (*A)[CB_C] = reinterpret_cast<float2 (*)[CB_C]>(smem);  // [128][32]
+    float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);  // [128][33]
     const int c = tid & (CB_C - 1);
     constexpr int PER = FT_BM * CB_C / 256;  // 16
     int valid = FT_BM;
-    const int levels = (a.dbg & 2) ? 0 : t.G.levels;
-    for (int l = 0; l < levels; ++l) {
+    for (int l = 0; l < t.G.levels; ++l) {
         const int st = 1 << l;
         valid -= st;
         const float2 w = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
@@ -450,16 +449,18 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const FusedTile& t
         }
         __syncthreads();
     }
-    if (a.dbg & 4) return;
-    for (int idx = tid; idx < t.S * CB_C; idx += 256) {
-        const int j = idx / CB_C;
-        const int f = t.f0 + j;
-        if (f < a.n_frames) a.X[(size_t)f * a.xc + t.nt * CB_C + c] = A[j][c];
+    // lanes walk the frames of one column: 512-byte runs in memory, conflict-free LDS reads
+    const int j = tid & (FT_BM - 1);
+    const int f = t.f0 + j;
+    if (j < t.S && f < a.n_frames) {
+        float2* dst = a.X + (size_t)(t.nt * CB_C) * a.ldf + f;
+#pragma unroll 4
+        for (int cc = tid >> 7; cc < CB_C; cc += 2) dst[(size_t)cc * a.ldf] = A[j][cc];
     }
 }
 
 __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[FT_BM * FT_BN];  // 32 KB: staging buffers, then the P tile
+    __shared__ __attribute__((aligned(16))) float smem[FT_P_FLOATS];  // 33 KB: staging buffers, then the P tile
     float (*As)[FT_BM][FT_BK + 1] = reinterpret_cast<float (*)[FT_BM][FT_BK + 1]>(smem);                       // [2][128][17]
     float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * FT_BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -519,12 +520,12 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
     }
 #undef PVQ_FT_LOAD
 #undef PVQ_FT_STORE
-    // P tile -> LDS as [row][64 floats] = [row][32 complex]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
+    // P tile -> LDS as [row][66 floats] = [row][32 complex + pad]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        smem[row * FT_BN + bc] = acc0[q];
-        smem[(row + 32) * FT_BN + bc] = acc1[q];
+        smem[row * (2 * FT_LDP) + bc] = acc0[q];
+        smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
     }
     __syncthreads();
     fused_tree_store(smem, T, a, tid);
@@ -594,7 +595,7 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(&Bs[p][b_n][b_c]) = rb[p];
     };
-    const int n_iter = (a.dbg & 1) ? 0 : a.K / FB_BK;
+    const int n_iter = a.K / FB_BK;
     const int ar = wm * 64 + (lane & 31), kh = (lane >> 5) * 8, bc = wn * 32 + (lane & 31);
     load(0);
     for (int it = 0; it < n_iter; ++it) {
@@ -654,8 +655,8 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        smem[row * FT_BN + bc] = acc0[q];
-        smem[(row + 32) * FT_BN + bc] = acc1[q];
+        smem[row * (2 * FT_LDP) + bc] = acc0[q];
+        smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
     }
     __syncthreads();
     fused_tree_store(smem, T, a, tid);
@@ -691,8 +692,8 @@ static int gemm_variant_index() {
 struct CombineArgs {
     const float* P;
     int p_rows;        // row capacity of the tile-major P
-    float2* X;         // [n_frames][xc]
-    int xc;
+    float2* X;         // column-major: X[col * ldf + frame]
+    int ldf;
     int n_frames;      // frames in this chunk
     int n_rows;        // rows of P present
     const int* tile_group;
@@ -704,7 +705,7 @@ struct CombineArgs {
 template <int CT, int CW, int MAXNB>
 __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
     constexpr int MAXR = CT + MAXNB - 1;
-    __shared__ float2 A[MAXR][CW];
+    __shared__ float2 A[MAXR][CW + 1];   // +1: the transposed store below reads a column per wave
     const int tid = threadIdx.x;
     const int col0 = blockIdx.x * CW;          // first complex column of this tile (global X column)
     const int f0 = blockIdx.y * CT;
@@ -746,134 +747,193 @@ __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < CT * CW; idx += 256) {
-        const int j = idx / CW;
+    {
+        const int j = tid & (CT - 1);
         const int f = f0 + j;
-        if (f < a.n_frames) a.X[(size_t)f * a.xc + col0 + c] = A[j][c];
+        if (f < a.n_frames)
+            for (int cc = tid / CT; cc < CW; cc += 256 / CT) a.X[(size_t)(col0 + cc) * a.ldf + f] = A[j][cc];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// dots + dB: x_vqt[k] = sum_e val[k][e] * X[col[k][e]]  (conj entries flagged), then power_to_db
+// kernel product + dB:  x_vqt[k] = sum_c K[k][c] X[c] (+ conjugate part), then power_to_db (vqt.rs:889-954)
+//
+// The rows of a window group's spectral kernel are band-limited wavelets: consecutive bins read
+// overlapping, nearly contiguous column ranges (27 % of a 16-bin x 70-column block is non-zero).  A block
+// of 16 bins is therefore a small dense real GEMM per frame tile,
+//     [32 frames x 2 kb] . [2 kb x 32]   (columns: Xr, Xi of kb spectrum columns; outputs: 16 x re, 16 x im),
+// one v_mfma_f32_32x32x2_f32 per spectrum column, with both operands read straight from memory in lane
+// order (X is column-major, so the 32 frames of a column are 256 contiguous bytes; the coefficient table
+// is stored as B operands and stays in L2).  The conjugate part (negative_filter_bank) lands in the same
+// B matrix with the signs of the Xi row flipped.  A workgroup owns FT frames and all bins: its four waves
+// walk disjoint lists of blocks, drop the dB values into LDS, and the frame-wide max / floor / shift of
+// power_to_db is applied from there.
 // ------------------------------------------------------------------------------------------------
-struct DotsArgs {
-    const float2* X;
-    int xc;
+struct BandArgs {
+    const float* X;            // column-major complex spectrum columns, as floats
+    int ldf;                   // frames per column (allocation stride)
     int n_frames;
     int n_bins;
-    int n_bins_pad;
-    const float2* ell_val;
-    const uint16_t* ell_col;
-    const uint16_t* row_len;   // per permuted row slot (wave-uniform, multiple of 4)
-    const uint16_t* row_bin;   // permuted row slot -> output bin (rows sorted by length so a wave's rows are alike)
-    float* out_db;     // [n_frames][n_bins]
-    float2* out_cplx;  // optional
+    int ldb;                   // LDS row stride of the dB tile
+    const BandBlock* blocks;
+    const float* B;
+    const int* list;           // [4][per_wave]
+    int per_wave;
+    int cnt[4];
+    float* out_db;             // [n_frames][n_bins]
+    float2* out_cplx;          // optional
 };
 
 #define PVQ_REF_POWER (0.3f * 0.3f)
 #define PVQ_A_MIN (1e-6f * 1e-6f)
 #define PVQ_TOP_DB 60.0f
 
-template <int DT_FB>
-__global__ __launch_bounds__(256) void blockdft_dots_db(DotsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* Xs = reinterpret_cast<float2*>(smem_raw);             // [DT_FB][xc]
-    float* red = reinterpret_cast<float*>(Xs + DT_FB * a.xc);     // [2][DT_FB][4]
-    const int tid = threadIdx.x;
-    const int f0 = blockIdx.x * DT_FB;
-    for (int idx = tid; idx < DT_FB * a.xc; idx += 256) {
-        const int fb = idx / a.xc, cc = idx - fb * a.xc;
-        const int f = f0 + fb;
-        Xs[idx] = (f < a.n_frames) ? a.X[(size_t)f * a.xc + cc] : make_float2(0.0f, 0.0f);
-    }
-    __syncthreads();
+// gfx950 lane-row swaps.  Inline asm: this compiler's two-result builtins (__builtin_amdgcn_permlane16_swap /
+// permlane32_swap) were seen to hand the same register to both results once inlined into a larger kernel.
+// x' = [x.rows 0, y.rows 0, x.rows 2, y.rows 2],  y' = [x.rows 1, y.rows 1, x.rows 3, y.rows 3]   (rows of 16 lanes)
+__device__ __forceinline__ void permlane16_swap(float& x, float& y) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+// x' = [x.lo, y.lo],  y' = [x.hi, y.hi]   (halves of 32 lanes)
+__device__ __forceinline__ void permlane32_swap(float& x, float& y) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+
+// wave-wide max / min by DPP (within rows of 16 lanes) and the gfx950 row / half swaps (across rows)
+#define PVQ_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, PVQ_DPP(v, 0xB1));    // quad_perm(1,0,3,2)
+    v = fmaxf(v, PVQ_DPP(v, 0x4E));    // quad_perm(2,3,0,1)
+    v = fmaxf(v, PVQ_DPP(v, 0x141));   // row_half_mirror
+    v = fmaxf(v, PVQ_DPP(v, 0x140));   // row_mirror
+    float x = v, y = v;
+    permlane16_swap(x, y);
+    v = fmaxf(x, y);
+    x = v;
+    y = v;
+    permlane32_swap(x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
+
+template <int MT>   // 32-frame MFMA row tiles per workgroup
+__global__ __launch_bounds__(256) void blockdft_banddots_db(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = blockIdx.x * (MT * 32);
+    const int n = lane & 31, kx = lane >> 5;
+    const int row = n & 15, part = n >> 4;
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
-    constexpr int PER = 4;  // n_bins <= 1024
-    float d[PER][DT_FB];
-    float mx[DT_FB], mn[DT_FB];
+    const size_t col_stride = (size_t)a.ldf * 2;   // floats between consecutive X columns
+    const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
+    for (int bi = 0; bi < n_blocks; ++bi) {
+        const BandBlock blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi])];
+        // MT == 2: a lane loads (Re, Im) of one of 64 frames; a half swap then leaves Re of frames 0..31 / Im of
+        // frames 0..31 in the two lane halves of one register (the A operand of row tile 0) and frames 32..63 in
+        // the other.  MT == 1: a lane loads the one float it feeds to the MFMA.
+        const float* xa = MT == 2 ? a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + lane) * 2
+                                  : a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + n) * 2 + kx;
+        const float2* bp = reinterpret_cast<const float2*>(a.B) + (size_t)blk.boff * 32 + lane;   // column pairs
+        f32x16 acc[MT];
 #pragma unroll
-    for (int fb = 0; fb < DT_FB; ++fb) {
-        mx[fb] = -3.40282347e+38f;
-        mn[fb] = 3.40282347e+38f;
-    }
-    int kbin[PER];
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int k = tid + t * 256;   // permuted row slot
-        kbin[t] = (k < a.n_bins) ? (int)a.row_bin[k] : 0;
-        if (k < a.n_bins) {
-            float2 acc[DT_FB];
+            for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
+        float2 av[BD_NS][BD_KU], bv[BD_NS][BD_KU / 2];
+        auto fetch = [&](int s, int c) {
 #pragma unroll
-            for (int fb = 0; fb < DT_FB; ++fb) acc[fb] = make_float2(0.0f, 0.0f);
-            // row_len is the longest row of this 64-bin group rounded up to 4 (shorter rows are padded
-            // with zero coefficients): the trip count is wave-uniform and the 4 entry loads of a step
-            // are independent, so the L2 latency of the kernel stream is paid once per 4 entries
-            const int len = a.row_len[k];
-            for (int e = 0; e < len; e += 4) {
-                float2 v[4];
-                uint32_t cc[4];
+            for (int u = 0; u < BD_KU / 2; ++u) bv[s][u] = bp[(size_t)(c / 2 + u) * 64];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[u] = a.ell_val[(size_t)(e + u) * a.n_bins_pad + k];
-                    cc[u] = a.ell_col[(size_t)(e + u) * a.n_bins_pad + k];
+            for (int u = 0; u < BD_KU; ++u) {
+                if (MT == 2)
+                    av[s][u] = *reinterpret_cast<const float2*>(xa + (size_t)(c + u) * col_stride);
+                else
+                    av[s][u].x = xa[(size_t)(c + u) * col_stride];
+            }
+        };
+        auto mul = [&](int s) {
+#pragma unroll
+            for (int u = 0; u < BD_KU; ++u) {
+                const float b = (u & 1) ? bv[s][u / 2].y : bv[s][u / 2].x;
+                if (MT == 2) {
+                    float t0 = av[s][u].x, t1 = av[s][u].y;
+                    permlane32_swap(t0, t1);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, b, acc[0], 0, 0, 0);
+                    acc[MT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, b, acc[MT - 1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][u].x, b, acc[0], 0, 0, 0);
                 }
+            }
+        };
+        // ring of BD_NS stages of BD_KU columns: BD_NS - 1 stages of operands in flight while one is multiplied.
+        // kb is a multiple of BD_KU; the fetches run up to (BD_NS - 1) * BD_KU columns past the block (in bounds
+        // by construction, never multiplied).
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int col = cc[u] & 0x7fffu;
-                    const float sg = (cc[u] & 0x8000u) ? -1.0f : 1.0f;   // conj(X) entries (vqt.rs:896-910)
-                    const float vxs = v[u].x * sg, vys = v[u].y * sg;
+        for (int s = 0; s < BD_NS - 1; ++s) fetch(s, s * BD_KU);
+        const int kb = __builtin_amdgcn_readfirstlane(blk.kb);
+        const int kb_full = kb - kb % (BD_NS * BD_KU);
+        int c = 0;
+        for (; c < kb_full; c += BD_NS * BD_KU) {   // steady state: no branches, exact load counting
 #pragma unroll
-                    for (int fb = 0; fb < DT_FB; ++fb) {
-                        const float2 x = Xs[fb * a.xc + col];
-                        acc[fb].x += v[u].x * x.x - vys * x.y;
-                        acc[fb].y += vxs * x.y + v[u].y * x.x;
+            for (int s = 0; s < BD_NS; ++s) {
+                fetch((s + BD_NS - 1) % BD_NS, c + (s + BD_NS - 1) * BD_KU);
+                mul(s);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < BD_NS - 1; ++s)         // remainder: the operands are already in flight
+            if (c + s * BD_KU < kb) mul(s);
+        // C layout: column n = lane & 31 (bin row = n & 15, re / im = n >> 4), frame = (q&3) + 8(q>>2) + 4(lane>>5).
+        // v_permlane16_swap brings the im column's value into the re column's lane.
+        float im[MT][16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float re = acc[mt][q], o = 0.0f;
+                permlane16_swap(re, o);   // o: rows 0 / 2 now hold the im columns' values
+                im[mt][q] = o;
+            }
+        if (part == 0 && row < blk.nrows) {
+            const int bin = blk.bin0 + row;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
+                    dbs[fr * a.ldb + bin] = acc[mt][q] * acc[mt][q] + im[mt][q] * im[mt][q];
+                }
+            if (a.out_cplx) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
+                        if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * a.n_bins + bin] = make_float2(acc[mt][q], im[mt][q]);
                     }
-                }
             }
-#pragma unroll
-            for (int fb = 0; fb < DT_FB; ++fb) {
-                if (a.out_cplx && f0 + fb < a.n_frames) a.out_cplx[(size_t)(f0 + fb) * a.n_bins + kbin[t]] = acc[fb];
-                const float ns = acc[fb].x * acc[fb].x + acc[fb].y * acc[fb].y;
-                const float v = 10.0f * log10f(fmaxf(ns, PVQ_A_MIN)) - ref_db;
-                d[t][fb] = v;
-                mx[fb] = fmaxf(mx[fb], v);
-                mn[fb] = fminf(mn[fb], v);
-            }
-        }
-    }
-#pragma unroll
-    for (int fb = 0; fb < DT_FB; ++fb) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mx[fb] = fmaxf(mx[fb], __shfl_xor(mx[fb], o));
-            mn[fb] = fminf(mn[fb], __shfl_xor(mn[fb], o));
-        }
-        if ((tid & 63) == 0) {
-            red[fb * 4 + (tid >> 6)] = mx[fb];
-            red[DT_FB * 4 + fb * 4 + (tid >> 6)] = mn[fb];
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int fb = 0; fb < DT_FB; ++fb) {
-        float m1 = red[fb * 4], m2 = red[DT_FB * 4 + fb * 4];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            m1 = fmaxf(m1, red[fb * 4 + w]);
-            m2 = fminf(m2, red[DT_FB * 4 + fb * 4 + w]);
+    // power_to_db per frame: a wave per frame, lanes over bins
+    for (int fr = wave; fr < MT * 32; fr += 4) {
+        if (f0 + fr >= a.n_frames) break;
+        float* rowp = dbs + fr * a.ldb;
+        float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
+        for (int k = lane; k < a.n_bins; k += 64) {
+            const float d = 10.0f * log10f(fmaxf(rowp[k], PVQ_A_MIN)) - ref_db;
+            rowp[k] = d;
+            mx = fmaxf(mx, d);
+            mn = fminf(mn, d);
         }
-        const float floor_db = m1 - PVQ_TOP_DB;
-        m2 = fmaxf(m2, floor_db);
-        if (f0 + fb < a.n_frames) {
-#pragma unroll
-            for (int t = 0; t < PER; ++t) {
-                const int k = tid + t * 256;
-                if (k < a.n_bins) {
-                    const float c = fmaxf(d[t][fb], floor_db);
-                    const float r = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
-                    a.out_db[(size_t)(f0 + fb) * a.n_bins + kbin[t]] = r;
-                }
-            }
+        mx = wave_max(mx);
+        mn = wave_min(mn);
+        const float floor_db = mx - PVQ_TOP_DB;
+        const float m2 = fmaxf(mn, floor_db);
+        float* dst = a.out_db + (size_t)(f0 + fr) * a.n_bins;
+        for (int k = lane; k < a.n_bins; k += 64) {
+            const float c = fmaxf(rowp[k], floor_db);
+            dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
         }
     }
 }
@@ -969,55 +1029,81 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
             }
         }
     }
-    // ELL-packed sparse kernel addressed by X column.  Rows are assigned to lanes in order of
-    // decreasing length so that the 64 rows a wave walks in lock step have similar lengths.
+    // Banded kernel product tables: per window group, blocks of BD_RB consecutive bins; a block walks the
+    // union of its rows' (compressed) columns.  B operand of column c, lane l (n = l & 31, k = l >> 5):
+    // output n = part * 16 + row, k = 0 multiplies Re X, k = 1 multiplies Im X:
+    //     y += v X        : re += vr Xr - vi Xi,  im += vi Xr + vr Xi      (filter_bank, vqt.rs:889-895)
+    //     y += conj(w X)  : re += wr Xr - wi Xi,  im += -wi Xr - wr Xi     (negative_filter_bank, vqt.rs:896-910)
     const int nb = (int)n_bins();
     t->n_bins_pad = (nb + 63) / 64 * 64;
-    struct RowRef { int bin; int g; uint32_t r; int len; };
-    std::vector<RowRef> rows;
+    std::vector<BandBlock> band;
+    std::vector<float> band_B;
+    // columns are stored in pairs: element (column c, lane l) lives at [(c / 2) * 64 + l] * 2 + (c & 1)
+    auto at = [](float* Bp, int c, int l) -> float& { return Bp[((size_t)(c >> 1) * 64 + l) * 2 + (c & 1)]; };
     for (size_t g = 0; g < groups.size(); ++g) {
         const CsrMatrix& A = groups[g].filter_bank;
         const CsrMatrix& Bm = groups[g].negative_filter_bank;
-        for (uint32_t r = 0; r < A.rows; ++r) {
-            int len = (int)(A.row_ptr[r + 1] - A.row_ptr[r]);
-            if (Bm.nnz() > 0) len += (int)(Bm.row_ptr[r + 1] - Bm.row_ptr[r]);
-            rows.push_back(RowRef{(int)(groups[g].first_bin + r), (int)g, r, len});
-        }
-    }
-    std::stable_sort(rows.begin(), rows.end(), [](const RowRef& x, const RowRef& y) { return x.len > y.len; });
-    std::vector<uint16_t> row_len(t->n_bins_pad, 0), row_bin(t->n_bins_pad, 0);
-    int ell_len = 0;
-    for (size_t i = 0; i < rows.size(); ++i) {
-        row_len[i] = (uint16_t)rows[i].len;
-        row_bin[i] = (uint16_t)rows[i].bin;
-        ell_len = std::max(ell_len, rows[i].len);
-    }
-    ell_len = (ell_len + 3) / 4 * 4;
-    for (int k0 = 0; k0 < t->n_bins_pad; k0 += 64) {  // wave-uniform, multiple of 4
-        uint16_t m = 0;
-        for (int k = k0; k < k0 + 64; ++k) m = std::max(m, row_len[k]);
-        m = (uint16_t)((m + 3) / 4 * 4);
-        for (int k = k0; k < k0 + 64; ++k) row_len[k] = m;
-    }
-    t->ell_len = ell_len;
-    std::vector<float2> ell_val((size_t)std::max(ell_len, 1) * t->n_bins_pad, make_float2(0.0f, 0.0f));
-    std::vector<uint16_t> ell_col((size_t)std::max(ell_len, 1) * t->n_bins_pad, 0);
-    for (size_t i = 0; i < rows.size(); ++i) {
-        const size_t g = (size_t)rows[i].g;
-        const uint32_t r = rows[i].r;
-        const CsrMatrix& A = groups[g].filter_bank;
-        const CsrMatrix& Bm = groups[g].negative_filter_bank;
         const int xoff = t->groups[g].tile0 * CB_C;
-        int e = 0;
-        for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q, ++e) {
-            ell_val[(size_t)e * t->n_bins_pad + i] = make_float2(A.values[q].re, A.values[q].im);
-            ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)(xoff + idx_of[g][A.col_idx[q]]);
-        }
-        if (Bm.nnz() > 0)
-            for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q, ++e) {
-                ell_val[(size_t)e * t->n_bins_pad + i] = make_float2(Bm.values[q].re, -Bm.values[q].im);
-                ell_col[(size_t)e * t->n_bins_pad + i] = (uint16_t)((xoff + idx_of[g][Bm.col_idx[q]]) | 0x8000u);
+        for (uint32_t r0 = 0; r0 < A.rows; r0 += BD_RB) {
+            const uint32_t r1 = std::min<uint32_t>(A.rows, r0 + BD_RB);
+            int lo = 1 << 30, hi = -1;
+            for (uint32_t r = r0; r < r1; ++r) {
+                for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
+                    lo = std::min(lo, idx_of[g][A.col_idx[q]]);
+                    hi = std::max(hi, idx_of[g][A.col_idx[q]]);
+                }
+                if (Bm.nnz() > 0)
+                    for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
+                        lo = std::min(lo, idx_of[g][Bm.col_idx[q]]);
+                        hi = std::max(hi, idx_of[g][Bm.col_idx[q]]);
+                    }
             }
+            BandBlock bb{};
+            bb.bin0 = (int)(groups[g].first_bin + r0);
+            bb.nrows = (int)(r1 - r0);
+            bb.boff = (int)(band_B.size() / 64);
+            if (hi < 0) {   // rows without coefficients: one all-zero stage
+                lo = 0;
+                hi = 0;
+            }
+            bb.x0 = xoff + lo;
+            bb.kb = ((hi - lo + 1) + BD_KU - 1) / BD_KU * BD_KU;
+            band_B.resize(band_B.size() + (size_t)bb.kb * 64, 0.0f);
+            float* Bp = band_B.data() + (size_t)bb.boff * 64;
+            for (uint32_t r = r0; r < r1; ++r) {
+                const int row = (int)(r - r0);
+                for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
+                    const int cc = idx_of[g][A.col_idx[q]] - lo;
+                    const float vr = A.values[q].re, vi = A.values[q].im;
+                    at(Bp, cc, 0 * 32 + row) += vr;        // k = 0 (Re X) -> re
+                    at(Bp, cc, 1 * 32 + row) += -vi;       // k = 1 (Im X) -> re
+                    at(Bp, cc, 0 * 32 + 16 + row) += vi;   // k = 0 -> im
+                    at(Bp, cc, 1 * 32 + 16 + row) += vr;   // k = 1 -> im
+                }
+                if (Bm.nnz() > 0)
+                    for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
+                        const int cc = idx_of[g][Bm.col_idx[q]] - lo;
+                        const float wr = Bm.values[q].re, wi = Bm.values[q].im;
+                        at(Bp, cc, 0 * 32 + row) += wr;
+                        at(Bp, cc, 1 * 32 + row) += -wi;
+                        at(Bp, cc, 0 * 32 + 16 + row) += -wi;
+                        at(Bp, cc, 1 * 32 + 16 + row) += -wr;
+                    }
+            }
+            band.push_back(bb);
+        }
+    }
+    band_B.resize(band_B.size() + (size_t)BD_NS * BD_KU * 64, 0.0f);   // the prefetch of the last block runs on past it
+    // blocks to waves: round robin in bin order, so that the four waves of a workgroup walk neighbouring blocks
+    // (whose column ranges overlap) at the same time and share the X columns through L1 / L2
+    std::vector<std::vector<int>> per_wave(4);
+    for (size_t i = 0; i < band.size(); ++i) per_wave[i & 3].push_back((int)i);
+    t->band_per_wave = 1;
+    for (int w = 0; w < 4; ++w) t->band_per_wave = std::max(t->band_per_wave, (int)per_wave[w].size());
+    std::vector<int> band_list((size_t)4 * t->band_per_wave, 0);
+    for (int w = 0; w < 4; ++w) {
+        t->band_cnt[w] = (int)per_wave[w].size();
+        for (size_t i = 0; i < per_wave[w].size(); ++i) band_list[(size_t)w * t->band_per_wave + i] = per_wave[w][i];
     }
     if (tile * CB_C >= 0x8000) {
         free_blockdft_tables(t);
@@ -1029,8 +1115,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
     t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
-              up(&t->d_comb_tw, comb_tw) && up(&t->d_ell_val, ell_val) && up(&t->d_ell_col, ell_col) &&
-              up(&t->d_row_len, row_len) && up(&t->d_row_bin, row_bin);
+              up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list);
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -1040,59 +1125,42 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     return PVQ_OK;
 }
 
-// Default: every kernel of a sub-batch on the caller's stream, peaks once over the whole batch.
-// Optional two-stream mode (PVQ_OVERLAP=1), buffers b = c & 1:
-//     s_gemm : [wait combine(c-2) done] GEMM(c) -> P[b]
-//     s_post : [wait GEMM(c) done] combine(c): P[b] -> X[b];  dots(c): X[b] -> out;  (peaks(c))
+// Every kernel of a sub-batch runs on the caller's stream; peaks once over the whole batch.  (A two-stream
+// variant that overlapped the GEMM of sub-batch c+1 with the memory-bound stages of c was measured slower:
+// the streams contend for the same CUs.)
 pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                      float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     pvq_status st = prepare_blockdft(hop);
     if (st != PVQ_OK) return st;
     BlockDftTables* t = dev_->block;
     const int ntot = t->n_tiles * GM_BN, xc = t->n_tiles * CB_C;
-    // Off by default: measured on MI355X the two streams contend (GEMM 55 -> 90 us, dots 40 -> 91 us per
-    // 8192 frames) and the batch gets slower (1.65 ms vs 1.18 ms per 65 536 frames).  Kept as a developer knob.
-    static const bool overlap_env = getenv("PVQ_OVERLAP") && atoi(getenv("PVQ_OVERLAP"));
-    const bool overlap = overlap_env && n_frames > chunk_frames();
     const size_t chunk = std::min(n_frames, chunk_frames());
     const size_t rows_cap = chunk + t->nb_max - 1;
-    const int n_buf = overlap ? 2 : 1;
-    const size_t p_bytes = rows_cap * ntot * sizeof(float) * n_buf, x_bytes = chunk * xc * sizeof(float2) * n_buf;
-    if (t->p_cap < p_bytes) {
-        if (t->d_P) PVQ_HIP(hipFree(t->d_P));
-        t->d_P = nullptr; t->p_cap = 0;
-        PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_P), p_bytes));
-        t->p_cap = p_bytes;
-    }
+    // X is column-major with a padded column stride (a power-of-two stride would put every column of a frame
+    // tile on the same memory channel); X_PAD_COLS zeroed columns follow the last one
+    const size_t ldf = (chunk + 63) / 64 * 64 + 64;
+    const size_t x_bytes = (size_t)(xc + X_PAD_COLS) * ldf * sizeof(float2);
     if (t->x_cap < x_bytes) {
         if (t->d_X) PVQ_HIP(hipFree(t->d_X));
         t->d_X = nullptr; t->x_cap = 0;
         PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_X), x_bytes));
+        PVQ_HIP(hipMemsetAsync(t->d_X, 0, x_bytes, stream));
         t->x_cap = x_bytes;
     }
-    hipStream_t s_gemm = stream, s_post = stream;
-    if (overlap) {
-        if (!t->streams_ready) {
-            PVQ_HIP(hipStreamCreateWithFlags(&t->s_gemm, hipStreamNonBlocking));
-            PVQ_HIP(hipStreamCreateWithFlags(&t->s_post, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) {
-                PVQ_HIP(hipEventCreateWithFlags(&t->ev_gemm[i], hipEventDisableTiming));
-                PVQ_HIP(hipEventCreateWithFlags(&t->ev_comb[i], hipEventDisableTiming));
-            }
-            PVQ_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
-            PVQ_HIP(hipEventCreateWithFlags(&t->ev_join_g, hipEventDisableTiming));
-            PVQ_HIP(hipEventCreateWithFlags(&t->ev_join_p, hipEventDisableTiming));
-            t->streams_ready = true;
+    const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
+    static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
+    const bool fused = fuse_env && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : FT_BK) == 0;
+    if (!fused) {
+        const size_t p_bytes = rows_cap * ntot * sizeof(float);
+        if (t->p_cap < p_bytes) {
+            if (t->d_P) PVQ_HIP(hipFree(t->d_P));
+            t->d_P = nullptr; t->p_cap = 0;
+            PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_P), p_bytes));
+            t->p_cap = p_bytes;
         }
-        s_gemm = t->s_gemm;
-        s_post = t->s_post;
-        PVQ_HIP(hipEventRecord(t->ev_fork, stream));
-        PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_fork, 0));
-        PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_fork, 0));
     }
     const long long n_samples = (long long)(n_lead + n_frames * hop);
-    const bool use_bf = gemm_split_bf16_ && hop % BF_BK == 0;
-    if (use_bf && !t->d_Et) {
+    if (use_bf && fused && !t->d_Et) {
         // bf16 split of E^T (round-to-nearest-even on the bit patterns), built on first use
         auto to_bf16 = [](float f) -> uint16_t {
             uint32_t u;
@@ -1123,45 +1191,30 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     const int nb = (int)n_bins();
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     const GemmVariant& gv = kGemmVariants[gemm_variant_index()];
+    float2* X = t->d_X;
     for (size_t c = 0; c < n_chunks; ++c) {
-        const int b = overlap ? (int)(c & 1) : 0;
-        float* P = t->d_P + (size_t)b * rows_cap * ntot;
-        float2* X = t->d_X + (size_t)b * chunk * xc;
         const size_t fbeg = c * chunk;
         const size_t nf = std::min(chunk, n_frames - fbeg);
-        const int n_rows = (int)(nf + t->nb_max - 1);
-        GemmArgs ga;
         // rebase the stream so that every byte offset of this launch fits 32 bits
         const long long first_needed = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop -
                                        (long long)plan_.params.n_fft;
         const long long rebase = std::max<long long>(0, std::min<long long>(first_needed, n_samples));
         const long long extent = std::min<long long>(n_samples - rebase, (long long)(nf + 2) * (long long)hop +
                                                                             (long long)plan_.params.n_fft + 4096);
-        ga.pcm_base = d_pcm + rebase;
-        ga.pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
-        ga.E = t->d_E;
-        ga.ld = ntot;
-        ga.P = P;
-        ga.n_rows = n_rows;
-        ga.K = (int)hop;
-        ga.tile_s = t->d_tile_s;
-        ga.base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
-        ga.n_col_tiles = t->n_tiles * GM_BN / gv.bn;
-        ga.p_rows = (int)rows_cap;
-        const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
-        static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
-        const bool fused = fuse_env && !overlap && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : FT_BK) == 0;
+        const float* pcm_base = d_pcm + rebase;
+        const unsigned pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
+        const long long base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
         if (fused) {
             GemmTreeArgs fa;
-            fa.pcm_base = ga.pcm_base;
-            fa.pcm_bytes = ga.pcm_bytes;
+            fa.pcm_base = pcm_base;
+            fa.pcm_bytes = pcm_bytes;
             fa.E = t->d_E;
             fa.ld = ntot;
             fa.X = X;
-            fa.xc = xc;
+            fa.ldf = (int)ldf;
             fa.n_frames = (int)nf;
             fa.K = (int)hop;
-            fa.base = ga.base;
+            fa.base = base;
             fa.n_groups = t->n_groups;
             int off = 0;
             for (int g = 0; g < t->n_groups; ++g) {
@@ -1174,96 +1227,75 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
             fa.Et = t->d_Et;
-            fa.dbg = getenv("PVQ_DBG") ? atoi(getenv("PVQ_DBG")) : 0;
-            slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
-            if (use_bf) {
-                hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3, dim3(off), dim3(256), 0, s_gemm, fa);
-            } else {
-                hipLaunchKernelGGL(blockdft_gemm_tree, dim3(off), dim3(256), 0, s_gemm, fa);
-            }
-            slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
+            slot_begin(SLOT_BLOCKDFT_GEMM, stream);
+            if (use_bf)
+                hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3, dim3(off), dim3(256), 0, stream, fa);
+            else
+                hipLaunchKernelGGL(blockdft_gemm_tree, dim3(off), dim3(256), 0, stream, fa);
+            slot_end(SLOT_BLOCKDFT_GEMM, stream);
         } else {
-            if (overlap && c >= 2) PVQ_HIP(hipStreamWaitEvent(s_gemm, t->ev_comb[b], 0));  // combine(c-2) is done with P[b]
-            slot_begin(SLOT_BLOCKDFT_GEMM, s_gemm);
-            if (use_bf) {
-                GemmBfArgs gb;
-                gb.pcm_base = ga.pcm_base;
-                gb.pcm_bytes = ga.pcm_bytes;
-                gb.Et = t->d_Et;
-                gb.ntot = ntot;
-                gb.P = P;
-                gb.n_rows = n_rows;
-                gb.K = (int)hop;
-                gb.tile_s = t->d_tile_s;
-                gb.base = ga.base;
-                gb.n_col_tiles = t->n_tiles;
-                gb.p_rows = (int)rows_cap;
-                const int mt8 = (((n_rows + BF_BM - 1) / BF_BM) + 7) / 8 * 8;
-                hipLaunchKernelGGL(blockdft_gemm_bf16x3, dim3(gb.n_col_tiles * mt8), dim3(256), 0, s_gemm, gb);
-            } else {
-                hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, s_gemm, ga);
-            }
-            slot_end(SLOT_BLOCKDFT_GEMM, s_gemm);
-            if (overlap) {
-                PVQ_HIP(hipEventRecord(t->ev_gemm[b], s_gemm));
-                PVQ_HIP(hipStreamWaitEvent(s_post, t->ev_gemm[b], 0));
-            }
+            const int n_rows = (int)(nf + t->nb_max - 1);
+            GemmArgs ga;
+            ga.pcm_base = pcm_base;
+            ga.pcm_bytes = pcm_bytes;
+            ga.E = t->d_E;
+            ga.ld = ntot;
+            ga.P = t->d_P;
+            ga.n_rows = n_rows;
+            ga.K = (int)hop;
+            ga.tile_s = t->d_tile_s;
+            ga.base = base;
+            ga.n_col_tiles = t->n_tiles * GM_BN / gv.bn;
+            ga.p_rows = (int)rows_cap;
+            const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
+            slot_begin(SLOT_BLOCKDFT_GEMM, stream);
+            hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, stream, ga);
+            slot_end(SLOT_BLOCKDFT_GEMM, stream);
             CombineArgs ca;
-            ca.P = P;
+            ca.P = t->d_P;
             ca.p_rows = (int)rows_cap;
             ca.X = X;
-            ca.xc = xc;
+            ca.ldf = (int)ldf;
             ca.n_frames = (int)nf;
             ca.n_rows = n_rows;
             ca.tile_group = t->d_tile_group;
             ca.groups = t->d_groups;
             ca.comb_tw = t->d_comb_tw;
-            slot_begin(SLOT_BLOCKDFT_COMBINE, s_post);
+            slot_begin(SLOT_BLOCKDFT_COMBINE, stream);
             if (t->nb_max <= 64)
                 hipLaunchKernelGGL((blockdft_combine<128, 16, 64>), dim3(t->n_tiles * 2, (unsigned)((nf + 127) / 128)), dim3(256), 0,
-                                   s_post, ca);
+                                   stream, ca);
             else
                 hipLaunchKernelGGL((blockdft_combine<CB_T, 16, 256>), dim3(t->n_tiles * 2, (unsigned)((nf + CB_T - 1) / CB_T)), dim3(256),
-                                   0, s_post, ca);
-            slot_end(SLOT_BLOCKDFT_COMBINE, s_post);
-            if (overlap) PVQ_HIP(hipEventRecord(t->ev_comb[b], s_post));
+                                   0, stream, ca);
+            slot_end(SLOT_BLOCKDFT_COMBINE, stream);
         }
-        DotsArgs da;
-        da.X = X;
-        da.xc = xc;
+        BandArgs da;
+        da.X = reinterpret_cast<const float*>(X);
+        da.ldf = (int)ldf;
         da.n_frames = (int)nf;
         da.n_bins = nb;
-        da.n_bins_pad = t->n_bins_pad;
-        da.ell_val = t->d_ell_val;
-        da.ell_col = t->d_ell_col;
-        da.row_len = t->d_row_len;
-        da.row_bin = t->d_row_bin;
+        da.ldb = t->n_bins_pad + 4;   // 4 rows apart (the two lane halves of a C tile) land 16 banks apart
+        da.blocks = t->d_band;
+        da.B = t->d_band_B;
+        da.list = t->d_band_list;
+        da.per_wave = t->band_per_wave;
+        for (int w = 0; w < 4; ++w) da.cnt[w] = t->band_cnt[w];
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
-        const size_t lds = sizeof(float2) * 4 * xc + sizeof(float) * 2 * 4 * 4;
-        slot_begin(SLOT_BLOCKDFT_DOTS, s_post);
-        hipLaunchKernelGGL(blockdft_dots_db<4>, dim3((unsigned)((nf + 3) / 4)), dim3(256), lds, s_post, da);
-        slot_end(SLOT_BLOCKDFT_DOTS, s_post);
-        if (pk && overlap) {
-            // peaks of this sub-batch right behind its dB rows, beside the next sub-batch's GEMM
-            PeakParamsDev p2 = *pk;
-            const size_t words = (nb + 31) / 32;
-            if (p2.mask) p2.mask += fbeg * words;
-            if (p2.count) p2.count += fbeg;
-            if (p2.center) p2.center += fbeg * p2.max_peaks;
-            if (p2.size) p2.size += fbeg * p2.max_peaks;
-            slot_begin(SLOT_PEAKS, s_post);
-            pvq_status ps = launch_peaks_kernel(d_out_db + fbeg * nb, nf, p2, s_post);
-            slot_end(SLOT_PEAKS, s_post);
-            if (ps != PVQ_OK) return ps;
+        slot_begin(SLOT_BLOCKDFT_DOTS, stream);
+        static const int mt_env = getenv("PVQ_DOTS_MT") ? atoi(getenv("PVQ_DOTS_MT")) : 0;   // developer knob
+        const int mt = mt_env ? mt_env : (t->n_bins_pad <= 256 ? 2 : 1);
+        if (mt == 2) {
+            const size_t lds = sizeof(float) * 64 * da.ldb;
+            hipLaunchKernelGGL(blockdft_banddots_db<2>, dim3((unsigned)((nf + 63) / 64)), dim3(256), lds, stream, da);
+        } else {
+            const size_t lds = sizeof(float) * 32 * da.ldb;
+            hipLaunchKernelGGL(blockdft_banddots_db<1>, dim3((unsigned)((nf + 31) / 32)), dim3(256), lds, stream, da);
         }
+        slot_end(SLOT_BLOCKDFT_DOTS, stream);
     }
-    if (overlap) {
-        PVQ_HIP(hipEventRecord(t->ev_join_g, s_gemm));
-        PVQ_HIP(hipEventRecord(t->ev_join_p, s_post));
-        PVQ_HIP(hipStreamWaitEvent(stream, t->ev_join_g, 0));
-        PVQ_HIP(hipStreamWaitEvent(stream, t->ev_join_p, 0));
-    } else if (pk) {
+    if (pk) {
         slot_begin(SLOT_PEAKS, stream);
         pvq_status ps = launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
         slot_end(SLOT_PEAKS, stream);
