@@ -344,7 +344,7 @@ class Vqt:
         _check(self._L.pvq_vqt_set_algo(self._h, algo))
 
     def set_gemm_precision(self, precision: int) -> None:
-        """GEMM_F32 (exact fp32 MFMA, default) or GEMM_BF16X3 (split-bf16 on the bf16 matrix cores)"""
+        """GEMM_BF16X3 (split-bf16 on the bf16 matrix cores, fp32 accumulate; default) or GEMM_F32 (fp32 MFMA)"""
         _check(self._L.pvq_vqt_set_gemm_precision(self._h, precision))
 
     def blockdft_columns(self) -> int:

@@ -535,8 +535,14 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
 // planes (six v_mfma_f32_32x32x16_bf16 per fp32 product block, see blockdft_gemm_bf16x3).  The PCM tile
 // is split while it is staged (16 consecutive samples per thread: b128 loads, b128 LDS writes); E comes
 // pre-split.  LDS: 3 x (128 + 64) rows x 40 bf16 = 45 KB of staging, aliased by the 32 KB P tile.
-constexpr int FB_BK = 32, FB_LD = FB_BK + 8;
-constexpr int FB_LDS_BYTES = 3 * (FT_BM + FT_BN) * FB_LD * 2;
+constexpr int FB_BK = 32;
+constexpr int FB_PLANE = (FT_BM + FT_BN) * FB_BK;            // bf16 elements of one plane: 128 PCM rows, then 64 E^T rows
+constexpr int FB_STAGE_BYTES = 3 * FB_PLANE * 2;             // 36 864 B
+constexpr int FB_LDS_BYTES = FB_STAGE_BYTES > FT_P_FLOATS * 4 ? FB_STAGE_BYTES : FT_P_FLOATS * 4;
+// element offset of the 8-sample chunk `ch` (0..3) of row `row` inside a plane.  Rows are 64 bytes, unpadded; the
+// chunk index is XORed with (row / 4) % 4, which makes the b128 fragment reads (16 consecutive rows, one chunk),
+// the PCM staging writes (8 rows x 2 chunks) and the E^T staging writes (4 rows x 4 chunks) bank-conflict free.
+__device__ __forceinline__ int fb_off(int row, int ch) { return row * FB_BK + ((ch ^ ((row >> 2) & 3)) << 3); }
 
 // K loop of the split-bf16 fused kernel.  VEC: the tile's samples all lie inside the stream, so each
 // thread's 16 consecutive samples come as four 16-byte loads; otherwise (tiles that touch the stream start
@@ -544,15 +550,13 @@ constexpr int FB_LDS_BYTES = 3 * (FT_BM + FT_BN) * FB_LD * 2;
 template <bool VEC>
 __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsigned char* smem_raw, unsigned a_off0, const __bf16* e_ptr,
                                                    int tid, f32x16& acc0, f32x16& acc1) {
-    __bf16 (*As)[FT_BM][FB_LD] = reinterpret_cast<__bf16 (*)[FT_BM][FB_LD]>(smem_raw);
-    __bf16 (*Bs)[FT_BN][FB_LD] = reinterpret_cast<__bf16 (*)[FT_BN][FB_LD]>(smem_raw + 3 * FT_BM * FB_LD * 2);
+    __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
     const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
     // A staging: thread -> (row = tid / 2, 16 consecutive k); B staging: thread -> (n = tid / 4, 8 consecutive k) x 3 planes
-    const int a_row = tid >> 1, a_k = (tid & 1) * 16;
-    const int b_n = tid >> 2, b_c = (tid & 3) * 8;
+    const int a_row = tid >> 1, b_n = tid >> 2;
     const size_t plane = (size_t)a.ld * a.K;
     float ra[16];
     bf16x8 rb[3];
@@ -588,15 +592,17 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
                 vm[q] = mid;
                 vl[q] = (__bf16)(r1 - (float)mid);
             }
-            *reinterpret_cast<bf16x8*>(&As[0][a_row][a_k + 8 * h]) = vh;
-            *reinterpret_cast<bf16x8*>(&As[1][a_row][a_k + 8 * h]) = vm;
-            *reinterpret_cast<bf16x8*>(&As[2][a_row][a_k + 8 * h]) = vl;
+            const int o = fb_off(a_row, (tid & 1) * 2 + h);
+            *reinterpret_cast<bf16x8*>(lds + o) = vh;
+            *reinterpret_cast<bf16x8*>(lds + FB_PLANE + o) = vm;
+            *reinterpret_cast<bf16x8*>(lds + 2 * FB_PLANE + o) = vl;
         }
+        const int ob = fb_off(FT_BM + b_n, tid & 3);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(&Bs[p][b_n][b_c]) = rb[p];
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(lds + p * FB_PLANE + ob) = rb[p];
     };
     const int n_iter = a.K / FB_BK;
-    const int ar = wm * 64 + (lane & 31), kh = (lane >> 5) * 8, bc = wn * 32 + (lane & 31);
+    const int ar = wm * 64 + (lane & 31), kh = lane >> 5, bc = FT_BM + wn * 32 + (lane & 31);
     load(0);
     for (int it = 0; it < n_iter; ++it) {
         store();
@@ -607,9 +613,9 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
             bf16x8 a0[3], a1[3], bv[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                a0[p] = *reinterpret_cast<const bf16x8*>(&As[p][ar][kk * 16 + kh]);
-                a1[p] = *reinterpret_cast<const bf16x8*>(&As[p][ar + 32][kk * 16 + kh]);
-                bv[p] = *reinterpret_cast<const bf16x8*>(&Bs[p][bc][kk * 16 + kh]);
+                a0[p] = *reinterpret_cast<const bf16x8*>(lds + p * FB_PLANE + fb_off(ar, kk * 2 + kh));
+                a1[p] = *reinterpret_cast<const bf16x8*>(lds + p * FB_PLANE + fb_off(ar + 32, kk * 2 + kh));
+                bv[p] = *reinterpret_cast<const bf16x8*>(lds + p * FB_PLANE + fb_off(bc, kk * 2 + kh));
             }
             // smallest terms first
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], bv[1], acc0, 0, 0, 0);  // mid*mid

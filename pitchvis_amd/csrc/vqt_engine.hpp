@@ -100,7 +100,7 @@ class Vqt {
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
     bool profiling_ = false;
-    bool gemm_split_bf16_ = false;
+    bool gemm_split_bf16_ = true;   // default PVQ_GEMM_BF16X3 (same parity bars as the fp32 MFMA form, ~1.3x faster)
     uint32_t last_frames_per_launch_ = 0;
     static constexpr int kMaxTimedLaunches = 512;
     std::vector<hipEvent_t> ev_[N_SLOTS][2];  // event pool, grown on demand
