@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 F_ALG_FLOP_PER_FRAME = 1.12e6       # 5 rFFTs (2.5 N log2 N) + 8 flop per kernel non-zero + dB/peaks
 B_ALG_BYTES_PER_FRAME = 2064.0      # hop*4 new input + 252*4 dB out + 8*4 peak mask
 PEAK_FP32_TFLOPS = 157.3            # MI355X fp32 dense MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split form spends 6 bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0               # HBM3E spec peak
 
 SR, HOP, N_BINS = 48000.0, 256, 252
@@ -94,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=65536, help="frames (hops) per GPU per step")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "blockdft"])
+    ap.add_argument("--gemm", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="arithmetic of the block-DFT GEMM: 3-way bf16 split on the bf16 matrix cores (default) or fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the plumbing on one GPU)")
@@ -129,6 +132,7 @@ def main():
     params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, 7, 36))
     vqt = P.Vqt.new(params, device=device_index)
     vqt.set_algo({"auto": P.ALGO_AUTO, "fft": P.ALGO_FFT, "blockdft": P.ALGO_BLOCKDFT}[args.algo])
+    vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
     assert vqt.n_bins == N_BINS
 
     # this rank's shard of a world*F-frame stream: its hops plus the window-union halo
@@ -169,6 +173,20 @@ def main():
     kernel_n = vqt.last_kernel_launches()
     fpl = vqt.last_frames_per_launch()
     vqt.set_profiling(False)
+    # the other GEMM arithmetic, same workload, reported beside the headline (rank-local, not part of `value`)
+    other = "f32" if args.gemm == "bf16x3" else "bf16x3"
+    vqt.set_gemm_precision(P.GEMM_F32 if other == "f32" else P.GEMM_BF16X3)
+    step()
+    torch.cuda.synchronize()
+    vqt.set_profiling(True)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt_other = time.perf_counter() - t1
+    kernel_ms_other = vqt.last_kernel_ms()
+    vqt.set_profiling(False)
+    vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
     if world > 1:
         t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,6 +202,8 @@ def main():
         dom_s = dom[1] * 1e-3
         tflops = F_ALG_FLOP_PER_FRAME * fpl / dom_s / 1e12
         gpu_ms_per_step = sum(kernel_ms[k] * kernel_n.get(k, 0) for k in kernel_ms) / args.steps
+        split = args.gemm == "bf16x3" and vqt.last_algo() == P.ALGO_BLOCKDFT
+        peak = PEAK_BF16_TFLOPS / 6.0 if split else PEAK_FP32_TFLOPS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -214,6 +234,8 @@ def main():
                 "hop": HOP,
                 "n_bins": N_BINS,
                 "algo": {P.ALGO_FFT: "fft", P.ALGO_BLOCKDFT: "blockdft"}.get(vqt.last_algo(), "auto"),
+                "gemm_arith": ("fp32 operands as 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate "
+                               "(error at fp32 rounding level, same parity bars)" if split else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
                 "sharding": f"frames x{world}, halo {vqt.window_union - HOP} samples, no collective",
             },
             "roofline": {
@@ -222,14 +244,17 @@ def main():
                 "bound": "mfma",
                 "kernel": dom[0],
                 "achieved": round(tflops, 3),
-                "peak": PEAK_FP32_TFLOPS,
+                "peak": round(peak, 1),
                 "unit": "TFLOP/s",
-                "frac": round(tflops / PEAK_FP32_TFLOPS, 5),
+                "frac": round(tflops / peak, 5),
                 "traffic": traffic,
                 "alg_flop_per_frame": F_ALG_FLOP_PER_FRAME,
-                "note": "achieved = algorithmic flop (FFT-route count, SURVEY 8d) x frames per launch / mean launch time of "
-                        "the kernel with the largest GPU time; the block-DFT path executes fewer flop than that count "
-                        "(hop blocks are shared by up to 64 frames), see executed_gemm_tflops and DESIGN.md 4-5",
+                "note": "achieved = algorithmic fp32 flop (FFT-route count, SURVEY 8d) x frames per launch / mean launch time of "
+                        "the kernel with the largest GPU time; peak = dense fp32 MFMA peak (157.3) for the fp32 GEMM, or the "
+                        "dense bf16 MFMA peak / 6 (2500 / 6 = 416.7 fp32-equivalent) for the split-bf16 GEMM; the block-DFT "
+                        "path executes fewer flop than the FFT-route count (hop blocks are shared by up to 64 frames), see "
+                        "executed_gemm_tflops (fp32-equivalent, without the 1.2x row recomputation of the fused tiles) and "
+                        "DESIGN.md 4-5",
                 "frames_per_launch": fpl,
                 "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "launches_per_step": {k: kernel_n.get(k, 0) // args.steps for k in kernel_ms},
@@ -238,7 +263,7 @@ def main():
                                          if "blockdft_gemm" in kernel_ms and vqt.blockdft_columns() else None),
                 # whole path (all kernels of a step) against the same fp32 roof
                 "path_tflops": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12, 3),
-                "path_frac": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 5),
+                "path_frac": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12 / peak, 5),
                 "hbm": {
                     "achieved": round(B_ALG_BYTES_PER_FRAME * fpl / dom_s / 1e9, 3),
                     "peak": PEAK_HBM_GBS,
@@ -247,6 +272,13 @@ def main():
                     "alg_bytes_per_frame": B_ALG_BYTES_PER_FRAME,
                 },
             },
+        }
+        out["alt_gemm"] = {
+            "gemm": other,
+            "value": round(F * args.steps / dt_other, 1),
+            "unit": "frames/s (this rank)",
+            "ms_per_step": round(dt_other / args.steps * 1e3, 4),
+            "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms_other.items()},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

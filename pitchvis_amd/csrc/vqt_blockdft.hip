@@ -14,9 +14,9 @@
 // log2(Nb)-level tree  A_{l+1}[j] = A_l[j] + phi^(2^l) A_l[j+2^l]  evaluated in LDS, then the
 // banded complex row dots (vqt.rs:889-910) and power_to_db (vqt.rs:922-954) as in the FFT path.
 //
-// Kernels:  blockdft_gemm (MFMA, LDS-tiled 128x64x32, double-buffered)
-//           blockdft_combine (one workgroup per 64 frames x 32 columns, tree in LDS)
-//           blockdft_dots_db (4 frames per workgroup, lane = output bin, ELL-packed kernel)
+// Kernels:  blockdft_gemm_tree[_bf16x3] (MFMA GEMM + combine tree fused; windows of <= 64 hop blocks)
+//           blockdft_gemm + blockdft_combine (the same two stages unfused, for longer windows)
+//           blockdft_banddots_db (kernel product as a banded MFMA GEMM + power_to_db)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -233,143 +233,7 @@ __global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
         }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Split-bf16 form of the same GEMM ("bf16x3", optional: pvq_vqt_set_gemm_precision): each fp32
-// operand is written exactly as hi + mid + lo with three bf16 values (8+8+8 mantissa bits) and the
-// product is accumulated in fp32 from the six partial products whose weight is >= 2^-16 (hh, hm, mh,
-// hl, lh, mm); the dropped terms are below 2^-24 of the product, i.e. at fp32 rounding level, and every
-// partial product of two bf16 numbers is exact in fp32.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate
-// of the fp32 MFMA, so six of them replace eight fp32 MFMAs at 6/16 of the matrix-pipe time.  E is split
-// once on the host (planes stored [plane][n][k], k contiguous = the B-operand fragment order); the PCM
-// tile is split while it is staged.  Measured: accuracy equal to the fp32 MFMA path (2.5-3.5e-7 of the
-// frame peak) but only ~1.2x faster — staging three bf16 planes of A through LDS (ds_write at
-// <= 80 B/clk/CU) is what bounds it, not the matrix pipe.
-// ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-struct GemmBfArgs {
-    const float* pcm_base;
-    unsigned pcm_bytes;
-    const __bf16* Et;         // [3][Ntot][K]
-    int ntot;
-    float* P;
-    int n_rows;
-    int K;
-    const long long* tile_s;
-    long long base;
-    int n_col_tiles;
-    int p_rows;
-};
-
-constexpr int BF_BM = 256, BF_BN = 64, BF_BK = 32, BF_LD = BF_BK + 8;  // LDS row stride in bf16 (80 B: 16-B aligned)
-
-__global__ __launch_bounds__(256) void blockdft_gemm_bf16x3(GemmBfArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[3][BF_BM][BF_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BF_BN][BF_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, bi = b >> 3;
-    const int nt = bi % a.n_col_tiles;
-    const int mt = (bi / a.n_col_tiles) * 8 + xcd;
-    if (mt * BF_BM >= a.n_rows) return;
-    const int j0 = mt * BF_BM;
-    const long long s = a.base + a.tile_s[nt];
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
-
-    // A staging: thread -> (row = tid/16 + 16*i, pair of k = 2*(tid%16)), 16 passes cover 256 rows x 32 k
-    constexpr int A_PASSES = BF_BM * BF_BK / 2 / 256;  // 16
-    const int a_row = tid >> 4, a_k = (tid & 15) * 2;
-    const unsigned a_off0 = (unsigned)((s + (long long)(j0 + a_row) * a.K + a_k) * 4ll);
-    const unsigned a_pass = (unsigned)(16 * a.K * 4);
-    float ra[A_PASSES][2];
-    // B staging: per plane 64 rows(n) x 32 k bf16 = 64 x 64 B: thread -> (n = tid/4, 16-B chunk = tid%4), 3 planes
-    const int b_n = tid >> 2, b_c = (tid & 3) * 8;
-    bf16x8 rb[3];
-    const size_t plane = (size_t)a.ntot * a.K;
-    const __bf16* e_ptr = a.Et + (size_t)(nt * BF_BN + b_n) * a.K + b_c;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int n_iter = a.K / BF_BK;
-    const int ar = wave * 64 + (lane & 31);  // wave tile: rows wave*64 .. +63, all 64 columns
-    const int kh = (lane >> 5) * 8;
-#define PVQ_BF_LOAD(k0)                                                                                          \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                   \
-            const unsigned off = a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u;                              \
-            ra[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));         \
-            ra[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4u, 0, 0));    \
-        }                                                                                                        \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const bf16x8*>(e_ptr + p * plane + (k0)); \
-    }
-#define PVQ_BF_STORE()                                                                                           \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                   \
-            const float x0 = ra[i][0], x1 = ra[i][1];                                                            \
-            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;                                                       \
-            const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;                                                \
-            const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;                                                       \
-            const __bf16 l0 = (__bf16)(r0 - (float)m0), l1 = (__bf16)(r1 - (float)m1);                           \
-            bf16x2 vh = {h0, h1}, vm = {m0, m1}, vl = {l0, l1};                                                  \
-            *reinterpret_cast<bf16x2*>(&As[0][a_row + 16 * i][a_k]) = vh;                                        \
-            *reinterpret_cast<bf16x2*>(&As[1][a_row + 16 * i][a_k]) = vm;                                        \
-            *reinterpret_cast<bf16x2*>(&As[2][a_row + 16 * i][a_k]) = vl;                                        \
-        }                                                                                                        \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(&Bs[p][b_n][b_c]) = rb[p];      \
-    }
-
-    PVQ_BF_LOAD(0);
-    for (int it = 0; it < n_iter; ++it) {
-        PVQ_BF_STORE();
-        __syncthreads();
-        if (it + 1 < n_iter) PVQ_BF_LOAD((it + 1) * BF_BK);
-#pragma unroll
-        for (int kk = 0; kk < BF_BK / 16; ++kk) {
-            bf16x8 av[2][3], bv[2][3];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(&As[p][ar + 32 * i][kk * 16 + kh]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[p][(lane & 31) + 32 * j][kk * 16 + kh]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][1], acc[i][j], 0, 0, 0);  // mid*mid
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][2], acc[i][j], 0, 0, 0);  // hi*lo
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[j][0], acc[i][j], 0, 0, 0);  // lo*hi
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], acc[i][j], 0, 0, 0);  // hi*mid
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][0], acc[i][j], 0, 0, 0);  // mid*hi
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);  // hi*hi
-                }
-        }
-        __syncthreads();
-    }
-#undef PVQ_BF_LOAD
-#undef PVQ_BF_STORE
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = nt * BF_BN + 32 * j + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = j0 + wave * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a.n_rows) a.P[((size_t)(col >> 6) * a.p_rows + row) * 64 + (col & 63)] = acc[i][j][r];
-            }
-        }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Fused form (windows of <= 64 hop blocks): the 128 x 32-complex-column tile of P never leaves the
@@ -531,10 +395,17 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
     fused_tree_store(smem, T, a, tid);
 }
 
-// Split-bf16 form of the fused kernel: same tile, same epilogue; the K loop multiplies hi/mid/lo bf16
-// planes (six v_mfma_f32_32x32x16_bf16 per fp32 product block, see blockdft_gemm_bf16x3).  The PCM tile
-// is split while it is staged (16 consecutive samples per thread: b128 loads, b128 LDS writes); E comes
-// pre-split.  LDS: 3 x (128 + 64) rows x 40 bf16 = 45 KB of staging, aliased by the 32 KB P tile.
+// Split-bf16 form of the fused kernel ("bf16x3", the default; pvq_vqt_set_gemm_precision): same tile, same
+// epilogue.  Each fp32 operand is written exactly as hi + mid + lo with three bf16 values (8+8+8 mantissa bits)
+// and the product is accumulated in fp32 from the six partial products whose weight is >= 2^-16 (hh, hm, mh, hl,
+// lh, mm); the dropped terms are below 2^-24 of the product, i.e. at fp32 rounding level, and every partial
+// product of two bf16 numbers is exact in fp32.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA,
+// so six of them replace eight fp32 MFMAs at 6/16 of the matrix-pipe time.  E is split once on the host (planes
+// stored [plane][n][k], k contiguous = the B-operand fragment order); the PCM tile is split while it is staged
+// (16 consecutive samples per thread: 16-byte loads, 16-byte LDS writes).  LDS: 3 planes x (128 + 64) rows x 32
+// bf16 = 36 KB of staging, swizzled instead of padded (4 workgroups per CU), aliased by the P tile.  Measured
+// accuracy equals the fp32 MFMA form (6e-7 of the frame peak); the K loop runs at ~35 % of the bf16 matrix peak,
+// bounded by the LDS staging and barrier structure of a 128 x 64 tile, not by the matrix pipe.
 constexpr int FB_BK = 32;
 constexpr int FB_PLANE = (FT_BM + FT_BN) * FB_BK;            // bf16 elements of one plane: 128 PCM rows, then 64 E^T rows
 constexpr int FB_STAGE_BYTES = 3 * FB_PLANE * 2;             // 36 864 B
@@ -666,30 +537,6 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a)
     }
     __syncthreads();
     fused_tree_store(smem, T, a, tid);
-}
-
-struct GemmVariant {
-    int bm, bn;
-    void (*kernel)(GemmArgs);
-    int threads;
-};
-static const GemmVariant kGemmVariants[] = {
-    {128, 64, blockdft_gemm<128, 64, 32, 2, 2>, 256},
-    {128, 128, blockdft_gemm<128, 128, 32, 2, 2>, 256},
-    {128, 64, blockdft_gemm<128, 64, 16, 2, 2>, 256},
-    {256, 64, blockdft_gemm<256, 64, 16, 4, 1>, 256},
-    {128, 128, blockdft_gemm<128, 128, 16, 2, 2>, 256},
-    {256, 128, blockdft_gemm<256, 128, 16, 4, 2>, 512},
-    {128, 64, blockdft_gemm<128, 64, 8, 2, 2>, 256},
-    {256, 64, blockdft_gemm<256, 64, 8, 4, 1>, 256},
-    {256, 64, blockdft_gemm<256, 64, 16, 4, 2>, 512},
-    {64, 64, blockdft_gemm<64, 64, 16, 1, 2>, 128},
-};
-static int gemm_variant_index() {
-    const char* e = getenv("PVQ_GEMM_VARIANT");  // developer knob; the default is the measured best
-    int v = e ? atoi(e) : 2;
-    if (v < 0 || v >= (int)(sizeof(kGemmVariants) / sizeof(kGemmVariants[0]))) v = 0;
-    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1001,8 +848,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         while ((1 << B.levels) < B.nb) ++B.levels;
         B.n_cols = (int)col_of[g].size();
         B.tile0 = tile;
-        const int pad_cols = kGemmVariants[gemm_variant_index()].bn / 2;  // complex columns per GEMM tile
-        B.n_tiles = ((B.n_cols + pad_cols - 1) / pad_cols) * (pad_cols / CB_C);
+        B.n_tiles = (B.n_cols + CB_C - 1) / CB_C;
         B.tw_off = tw_off;
         B.s_rel = (long long)groups[g].window_begin - (long long)plan_.params.n_fft;  // + n_lead + hop at launch
         tile += B.n_tiles;
@@ -1196,7 +1042,6 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     }
     const int nb = (int)n_bins();
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
-    const GemmVariant& gv = kGemmVariants[gemm_variant_index()];
     float2* X = t->d_X;
     for (size_t c = 0; c < n_chunks; ++c) {
         const size_t fbeg = c * chunk;
@@ -1251,11 +1096,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             ga.K = (int)hop;
             ga.tile_s = t->d_tile_s;
             ga.base = base;
-            ga.n_col_tiles = t->n_tiles * GM_BN / gv.bn;
+            ga.n_col_tiles = t->n_tiles;
             ga.p_rows = (int)rows_cap;
-            const int m_tiles8 = (((n_rows + gv.bm - 1) / gv.bm) + 7) / 8 * 8;
+            const int m_tiles8 = (((n_rows + 127) / 128) + 7) / 8 * 8;
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-            hipLaunchKernelGGL(gv.kernel, dim3(ga.n_col_tiles * m_tiles8), dim3(gv.threads), 0, stream, ga);
+            hipLaunchKernelGGL((blockdft_gemm<128, 64, 16, 2, 2>), dim3(ga.n_col_tiles * m_tiles8), dim3(256), 0, stream, ga);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
             CombineArgs ca;
             ca.P = t->d_P;
