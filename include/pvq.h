@@ -234,6 +234,68 @@ uint32_t pvq_analysis_state_get_peaks_continuous(const pvq_analysis_state *s, fl
 float pvq_analysis_state_scene_calmness(const pvq_analysis_state *s);            /* smoothed_scene_calmness.get() */
 float pvq_analysis_state_tuning_grid_inaccuracy(const pvq_analysis_state *s);    /* smoothed_tuning_grid_inaccuracy.get() */
 
+/* ------------------------------------------------------------------------------------------------
+ * Callers either side of the path: host code around the GPU frames.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* dagc::MonoAgc (dagc_fork/src/lib.rs:19-87).  create: PVQ_ERR_INVALID_ARG with the reference's Error text
+ * for a bad desired_output_rms / distortion_factor (lib.rs:36-49). */
+typedef struct pvq_mono_agc pvq_mono_agc;
+pvq_status pvq_mono_agc_create(float desired_output_rms, float distortion_factor, pvq_mono_agc **out);
+void pvq_mono_agc_destroy(pvq_mono_agc *a);
+void pvq_mono_agc_freeze_gain(pvq_mono_agc *a, int freeze);      /* lib.rs:62 */
+int pvq_mono_agc_is_gain_frozen(const pvq_mono_agc *a);           /* lib.rs:67 */
+float pvq_mono_agc_gain(const pvq_mono_agc *a);                   /* lib.rs:72 */
+void pvq_mono_agc_process(pvq_mono_agc *a, float *samples, size_t n);   /* lib.rs:76-86, in place */
+
+/* pitchvis_train as a batch (pitchvis_train/src/train.rs).
+ * chunk length: (delay_ms * sr / 1000) / 64 * 64, train.rs:128-129 */
+size_t pvq_train_chunk_samples(const pvq_vqt *v);
+/* train.rs:286-310 over n_chunks rendered chunks of `chunk` samples: downmix (l + r) / 2 (right may be NULL),
+ * silence gate (sum of squares < 1e-6 freezes the gain for the chunk), AGC in place.  mono_out
+ * [n_chunks * chunk]; gain_out [n_chunks] (may be NULL) = agc.gain() after each chunk. */
+pvq_status pvq_train_condition_stream(pvq_mono_agc *a, const float *left, const float *right, size_t n_chunks,
+                                      size_t chunk, float *mono_out, float *gain_out);
+/* train.rs:341 for every step-th chunk (STEP_SIZE_IN_CHUNKS = 3, train.rs:44), on the GPU: frame f = VQT dB of
+ * the last n_fft conditioned samples after chunk (f+1)*step (zeros before the stream, the ring buffer of
+ * train.rs:268-269).  out_db [n_chunks / step][n_bins]. */
+pvq_status pvq_train_frames_db(pvq_vqt *v, const float *mono, size_t n_chunks, size_t chunk, size_t step, float *out_db);
+/* train.rs:317-337, 347, 443-460: row f = n_bins dB values, then 128 targets from the active keys of frame
+ * f-1 (a key's value: largest (mix_left + mix_right) / 2 * agc_gain over its voices; target = value > 0.5).
+ * voice_ptr [n_frames + 1] indexes the voice arrays; agc_gain [n_frames].  out_rows [n_frames][n_bins + 128].
+ * PVQ_ERR_INVALID_ARG for a key outside 0..127 (the reference would panic). */
+pvq_status pvq_train_rows(const float *db, size_t n_frames, uint32_t n_bins, const uint32_t *voice_ptr,
+                          const int32_t *voice_key, const float *voice_gain_left, const float *voice_gain_right,
+                          const float *agc_gain, float *out_rows);
+/* train.rs:192-208: flat little-endian f32 .npy, shape (n,) */
+pvq_status pvq_npy_write_f32(const char *path, const float *data, uint64_t n);
+
+/* Streaming front end: the pitchvis_audio RingBuffer contract (pitchvis_audio/src/lib.rs:17-22,
+ * audio_desktop.rs:88-131) with the ring resident on the device.  The ring holds buf_size samples, zeros at
+ * start; push() is the audio callback: a chunk containing a non-finite sample is dropped (audio_desktop.rs:
+ * 97-100), otherwise the silence gate + MonoAgc(0.07, 0.0001) run over it (with_agc != 0), it is shifted into
+ * the ring (drain + extend) and gain / chunk_size_ms are updated.  frame_db() is the consumer of
+ * pitchvis_serial/src/main.rs:205-211: the VQT of the newest n_fft samples.  Not thread-safe: serialise push
+ * and frame_db like the reference's mutex does. */
+typedef struct pvq_stream pvq_stream;
+pvq_status pvq_stream_create(pvq_vqt *v, size_t buf_size, int with_agc, pvq_stream **out);
+void pvq_stream_destroy(pvq_stream *s);
+pvq_status pvq_stream_push(pvq_stream *s, const float *data, size_t n);
+float pvq_stream_gain(const pvq_stream *s);             /* RingBuffer.gain */
+float pvq_stream_chunk_size_ms(const pvq_stream *s);    /* RingBuffer.chunk_size_ms */
+pvq_status pvq_stream_frame_db(pvq_stream *s, float *out_db);
+/* host copy of the newest n_last samples of the ring (n_last <= buf_size) */
+pvq_status pvq_stream_read(pvq_stream *s, float *out, size_t n_last);
+
+/* pitchvis_colors::calculate_color (pitchvis_colors/src/lib.rs:86-117); colors: 12 RGB triples in [0, 1] */
+void pvq_calculate_color(uint16_t buckets_per_octave, float bucket, const float *colors, float gray_level,
+                         float easing_pow, float out_rgb[3]);
+/* pitchvis_serial::update_serial (pitchvis_serial/src/main.rs:122-175): 0xFF, 16-bit triple count (big endian),
+ * then one RGB triple (each byte <= 0xFE) per bucket.  center/size: AnalysisState::peaks_continuous.  out must
+ * hold 3 + 3 * n_buckets bytes; returns the number of bytes written. */
+size_t pvq_led_frame(uint32_t n_buckets, uint16_t buckets_per_octave, const float *center, const float *size,
+                     uint32_t n_peaks, const float *colors, float gray_level, float easing_pow, uint8_t *out);
+
 /* timing hook for bench.py: elapsed GPU milliseconds of the dominant kernel launches of the
  * last batch call, measured with HIP events on the stream the kernels were launched on.
  * Enable with pvq_vqt_set_profiling(v, 1) (resets the statistics); reading synchronises. */

@@ -22,6 +22,11 @@ EXPORTS = [
     "pvq_analysis_state_bin_to_frequency", "pvq_analysis_state_n_buckets", "pvq_analysis_state_get_field",
     "pvq_analysis_state_get_peaks", "pvq_analysis_state_get_peaks_continuous", "pvq_analysis_state_scene_calmness",
     "pvq_analysis_state_tuning_grid_inaccuracy",
+    "pvq_mono_agc_create", "pvq_mono_agc_destroy", "pvq_mono_agc_freeze_gain", "pvq_mono_agc_is_gain_frozen",
+    "pvq_mono_agc_gain", "pvq_mono_agc_process", "pvq_train_chunk_samples", "pvq_train_condition_stream",
+    "pvq_train_frames_db", "pvq_train_rows", "pvq_npy_write_f32", "pvq_stream_create", "pvq_stream_destroy",
+    "pvq_stream_push", "pvq_stream_gain", "pvq_stream_chunk_size_ms", "pvq_stream_frame_db", "pvq_stream_read",
+    "pvq_calculate_color", "pvq_led_frame",
 ]
 
 PVQ_OK = 0
@@ -152,5 +157,28 @@ def load():
     L.pvq_analysis_state_get_peaks_continuous.restype = C.c_uint32
     L.pvq_analysis_state_scene_calmness.argtypes = [vp]; L.pvq_analysis_state_scene_calmness.restype = C.c_float
     L.pvq_analysis_state_tuning_grid_inaccuracy.argtypes = [vp]; L.pvq_analysis_state_tuning_grid_inaccuracy.restype = C.c_float
+    ip, bp = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.pvq_mono_agc_create.argtypes = [C.c_float, C.c_float, C.POINTER(vp)]; L.pvq_mono_agc_create.restype = C.c_int
+    L.pvq_mono_agc_destroy.argtypes = [vp]
+    L.pvq_mono_agc_freeze_gain.argtypes = [vp, C.c_int]
+    L.pvq_mono_agc_is_gain_frozen.argtypes = [vp]; L.pvq_mono_agc_is_gain_frozen.restype = C.c_int
+    L.pvq_mono_agc_gain.argtypes = [vp]; L.pvq_mono_agc_gain.restype = C.c_float
+    L.pvq_mono_agc_process.argtypes = [vp, fp, C.c_size_t]
+    L.pvq_train_chunk_samples.argtypes = [vp]; L.pvq_train_chunk_samples.restype = C.c_size_t
+    L.pvq_train_condition_stream.argtypes = [vp, fp, fp, C.c_size_t, C.c_size_t, fp, fp]
+    L.pvq_train_condition_stream.restype = C.c_int
+    L.pvq_train_frames_db.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.c_size_t, fp]; L.pvq_train_frames_db.restype = C.c_int
+    L.pvq_train_rows.argtypes = [fp, C.c_size_t, C.c_uint32, up, ip, fp, fp, fp, fp]; L.pvq_train_rows.restype = C.c_int
+    L.pvq_npy_write_f32.argtypes = [C.c_char_p, fp, C.c_uint64]; L.pvq_npy_write_f32.restype = C.c_int
+    L.pvq_stream_create.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp)]; L.pvq_stream_create.restype = C.c_int
+    L.pvq_stream_destroy.argtypes = [vp]
+    L.pvq_stream_push.argtypes = [vp, fp, C.c_size_t]; L.pvq_stream_push.restype = C.c_int
+    L.pvq_stream_gain.argtypes = [vp]; L.pvq_stream_gain.restype = C.c_float
+    L.pvq_stream_chunk_size_ms.argtypes = [vp]; L.pvq_stream_chunk_size_ms.restype = C.c_float
+    L.pvq_stream_frame_db.argtypes = [vp, fp]; L.pvq_stream_frame_db.restype = C.c_int
+    L.pvq_stream_read.argtypes = [vp, fp, C.c_size_t]; L.pvq_stream_read.restype = C.c_int
+    L.pvq_calculate_color.argtypes = [C.c_uint16, C.c_float, fp, C.c_float, C.c_float, fp]
+    L.pvq_led_frame.argtypes = [C.c_uint32, C.c_uint16, fp, fp, C.c_uint32, fp, C.c_float, C.c_float, bp]
+    L.pvq_led_frame.restype = C.c_size_t
     _lib = L
     return L

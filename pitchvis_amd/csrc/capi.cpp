@@ -3,7 +3,12 @@
 #include <memory>
 
 #include "../../include/pvq.h"
+#include <cmath>
+#include <string>
+#include <vector>
+
 #include "analysis_host.hpp"
+#include "consumers_host.hpp"
 #include "vqt_engine.hpp"
 
 struct pvq_vqt {
@@ -11,6 +16,22 @@ struct pvq_vqt {
 };
 struct pvq_analysis_state {
     std::unique_ptr<pvq::AnalysisState> impl;
+};
+struct pvq_mono_agc {
+    pvq::MonoAgc impl;
+};
+// device-resident ring: the newest buf_size samples are d_ring[w - buf_size, w); compacted when the linear
+// buffer (4 x buf_size) runs out
+struct pvq_stream {
+    pvq_vqt* vqt = nullptr;
+    size_t buf_size = 0, cap = 0, w = 0;
+    float* d_ring = nullptr;
+    float* d_db = nullptr;
+    bool with_agc = false;
+    pvq::MonoAgc agc{0.07f, 0.0001f};   // audio_desktop.rs:93
+    float gain = 0.0f;                  // audio_desktop.rs:83
+    float chunk_size_ms = 0.0f;
+    std::vector<float> staging;
 };
 
 namespace {
@@ -362,5 +383,167 @@ uint32_t pvq_vqt_last_kernel_launches(pvq_vqt* v, uint32_t* out_n, uint32_t capa
 }
 uint32_t pvq_vqt_last_frames_per_launch(const pvq_vqt* v) { return v ? v->impl->last_frames_per_launch() : 0; }
 const char* pvq_vqt_kernel_name(uint32_t slot) { return pvq::Vqt::slot_name(slot); }
+
+// ------------------------------------------------------------------------------------------------
+// callers either side of the path
+// ------------------------------------------------------------------------------------------------
+pvq_status pvq_mono_agc_create(float desired_output_rms, float distortion_factor, pvq_mono_agc** out) {
+    if (!out) return null_handle();
+    *out = nullptr;
+    std::string why;
+    if (!pvq::MonoAgc::valid(desired_output_rms, distortion_factor, &why)) {
+        pvq::set_last_error(why);
+        return PVQ_ERR_INVALID_ARG;
+    }
+    *out = new pvq_mono_agc{pvq::MonoAgc(desired_output_rms, distortion_factor)};
+    return PVQ_OK;
+}
+void pvq_mono_agc_destroy(pvq_mono_agc* a) { delete a; }
+void pvq_mono_agc_freeze_gain(pvq_mono_agc* a, int freeze) {
+    if (a) a->impl.freeze_gain(freeze != 0);
+}
+int pvq_mono_agc_is_gain_frozen(const pvq_mono_agc* a) { return a && a->impl.is_gain_frozen() ? 1 : 0; }
+float pvq_mono_agc_gain(const pvq_mono_agc* a) { return a ? a->impl.gain() : 0.0f; }
+void pvq_mono_agc_process(pvq_mono_agc* a, float* samples, size_t n) {
+    if (a && samples) a->impl.process(samples, n);
+}
+
+size_t pvq_train_chunk_samples(const pvq_vqt* v) {
+    return v ? pvq::train_chunk_samples(v->impl->delay_seconds(), v->impl->params().sr) : 0;
+}
+pvq_status pvq_train_condition_stream(pvq_mono_agc* a, const float* left, const float* right, size_t n_chunks, size_t chunk,
+                                      float* mono_out, float* gain_out) {
+    if (!a || !left || !mono_out) return null_handle();
+    pvq::train_condition_stream(a->impl, left, right, n_chunks, chunk, mono_out, gain_out);
+    return PVQ_OK;
+}
+pvq_status pvq_train_frames_db(pvq_vqt* v, const float* mono, size_t n_chunks, size_t chunk, size_t step, float* out_db) {
+    if (!v || !mono || !out_db) return null_handle();
+    if (chunk == 0 || step == 0) {
+        pvq::set_last_error("chunk and step must be positive");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    const size_t n_frames = n_chunks / step;
+    if (n_frames == 0) return PVQ_OK;
+    return v->impl->calculate_batch_db(mono, 0, chunk * step, n_frames, out_db);
+}
+pvq_status pvq_train_rows(const float* db, size_t n_frames, uint32_t n_bins, const uint32_t* voice_ptr, const int32_t* voice_key,
+                          const float* voice_gain_left, const float* voice_gain_right, const float* agc_gain, float* out_rows) {
+    if (!db || !voice_ptr || !agc_gain || !out_rows) return null_handle();
+    std::string why;
+    if (!pvq::train_rows(db, n_frames, n_bins, voice_ptr, voice_key, voice_gain_left, voice_gain_right, agc_gain, out_rows, &why)) {
+        pvq::set_last_error(why);
+        return PVQ_ERR_INVALID_ARG;
+    }
+    return PVQ_OK;
+}
+pvq_status pvq_npy_write_f32(const char* path, const float* data, uint64_t n) {
+    if (!path || (!data && n)) return null_handle();
+    std::string why;
+    if (!pvq::npy_write_f32(path, data, n, &why)) {
+        pvq::set_last_error(why);
+        return PVQ_ERR_INVALID_ARG;
+    }
+    return PVQ_OK;
+}
+
+#define PVQ_CAPI_HIP(call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            pvq::set_last_error(std::string(#call) + " failed: " + hipGetErrorString(e_));  \
+            return PVQ_ERR_DEVICE;                                                          \
+        }                                                                                   \
+    } while (0)
+
+pvq_status pvq_stream_create(pvq_vqt* v, size_t buf_size, int with_agc, pvq_stream** out) {
+    if (!v || !out) return null_handle();
+    *out = nullptr;
+    const size_t n_fft = v->impl->params().n_fft;
+    if (buf_size < n_fft) {
+        pvq::set_last_error("ring buffer shorter than n_fft");
+        return PVQ_ERR_BAD_LENGTH;
+    }
+    if (!v->impl->has_device()) {
+        pvq::set_last_error("the streaming front end needs a GPU handle");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    auto s = std::make_unique<pvq_stream>();
+    s->vqt = v;
+    s->buf_size = buf_size;
+    s->cap = 4 * buf_size;
+    s->with_agc = with_agc != 0;
+    PVQ_CAPI_HIP(hipSetDevice(v->impl->device()));
+    PVQ_CAPI_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_ring), s->cap * sizeof(float)));
+    PVQ_CAPI_HIP(hipMemset(s->d_ring, 0, s->cap * sizeof(float)));
+    PVQ_CAPI_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_db), v->impl->n_bins() * sizeof(float)));
+    s->w = buf_size;
+    *out = s.release();
+    return PVQ_OK;
+}
+void pvq_stream_destroy(pvq_stream* s) {
+    if (!s) return;
+    if (s->d_ring) (void)hipFree(s->d_ring);
+    if (s->d_db) (void)hipFree(s->d_db);
+    delete s;
+}
+pvq_status pvq_stream_push(pvq_stream* s, const float* data, size_t n) {
+    if (!s || (!data && n)) return null_handle();
+    if (n == 0) return PVQ_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(data[i])) return PVQ_OK;   // audio_desktop.rs:97-100: the chunk is dropped
+    if (n > s->buf_size) {                            // Vec::drain(..n) would panic
+        pvq::set_last_error("chunk longer than the ring buffer");
+        return PVQ_ERR_BAD_LENGTH;
+    }
+    s->staging.assign(data, data + n);
+    if (s->with_agc) {
+        float sq = 0.0f;
+        for (size_t i = 0; i < n; ++i) sq += data[i] * data[i];     // audio_desktop.rs:101
+        s->agc.freeze_gain(sq < 1e-6f);                             // :102
+        s->agc.process(s->staging.data(), n);                       // :111 (over the newest samples of the ring)
+        s->gain = s->agc.gain();                                    // :112
+    }
+    PVQ_CAPI_HIP(hipSetDevice(s->vqt->impl->device()));
+    if (s->w + n > s->cap) {   // compact: newest buf_size samples to the front (ranges do not overlap: cap = 4 buf_size)
+        PVQ_CAPI_HIP(hipMemcpy(s->d_ring, s->d_ring + s->w - s->buf_size, s->buf_size * sizeof(float), hipMemcpyDeviceToDevice));
+        s->w = s->buf_size;
+    }
+    PVQ_CAPI_HIP(hipMemcpy(s->d_ring + s->w, s->staging.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    s->w += n;
+    s->chunk_size_ms = static_cast<float>(n) / s->vqt->impl->params().sr * 1000.0f;   // :118
+    return PVQ_OK;
+}
+float pvq_stream_gain(const pvq_stream* s) { return s ? s->gain : 0.0f; }
+float pvq_stream_chunk_size_ms(const pvq_stream* s) { return s ? s->chunk_size_ms : 0.0f; }
+pvq_status pvq_stream_frame_db(pvq_stream* s, float* out_db) {
+    if (!s || !out_db) return null_handle();
+    const size_t n_fft = s->vqt->impl->params().n_fft;
+    // one frame over the newest n_fft samples: n_lead = n_fft - 1 samples of history + a hop of 1
+    pvq_status st = s->vqt->impl->calculate_batch_db_device(s->d_ring + s->w - n_fft, n_fft - 1, 1, 1, s->d_db, nullptr, nullptr);
+    if (st != PVQ_OK) return st;
+    PVQ_CAPI_HIP(hipMemcpy(out_db, s->d_db, s->vqt->impl->n_bins() * sizeof(float), hipMemcpyDeviceToHost));
+    return PVQ_OK;
+}
+pvq_status pvq_stream_read(pvq_stream* s, float* out, size_t n_last) {
+    if (!s || !out) return null_handle();
+    if (n_last > s->buf_size) {
+        pvq::set_last_error("n_last exceeds the ring buffer");
+        return PVQ_ERR_BAD_LENGTH;
+    }
+    PVQ_CAPI_HIP(hipSetDevice(s->vqt->impl->device()));
+    PVQ_CAPI_HIP(hipMemcpy(out, s->d_ring + s->w - n_last, n_last * sizeof(float), hipMemcpyDeviceToHost));
+    return PVQ_OK;
+}
+
+void pvq_calculate_color(uint16_t buckets_per_octave, float bucket, const float* colors, float gray_level, float easing_pow,
+                         float out_rgb[3]) {
+    pvq::calculate_color(buckets_per_octave, bucket, reinterpret_cast<const float(*)[3]>(colors), gray_level, easing_pow, out_rgb);
+}
+size_t pvq_led_frame(uint32_t n_buckets, uint16_t buckets_per_octave, const float* center, const float* size, uint32_t n_peaks,
+                     const float* colors, float gray_level, float easing_pow, uint8_t* out) {
+    return pvq::led_frame(n_buckets, buckets_per_octave, center, size, n_peaks, reinterpret_cast<const float(*)[3]>(colors),
+                          gray_level, easing_pow, out);
+}
 
 }  // extern "C"

@@ -42,6 +42,7 @@ class Vqt {
     double delay_seconds() const { return plan_.delay_seconds; }  // vqt.rs:449
     uint32_t n_bins() const { return plan_.params.range.n_buckets(); }
     bool has_device() const { return device_id_ >= 0; }
+    int device() const { return device_id_; }
 
     // vqt.rs:866 (host pointers, synchronous)
     pvq_status calculate_vqt_instant_in_db(const float* x, size_t len, float* out_db);
