@@ -670,7 +670,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 
 template <int MT>   // 32-frame MFMA row tiles per workgroup
-__global__ __launch_bounds__(256) void blockdft_banddots_db(BandArgs a) {
+__global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
@@ -679,31 +679,42 @@ __global__ __launch_bounds__(256) void blockdft_banddots_db(BandArgs a) {
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     const size_t col_stride = (size_t)a.ldf * 2;   // floats between consecutive X columns
     const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
+    // MT == 2: a lane loads (Re, Im) of one of 64 frames; a half swap then leaves Re of frames 0..31 / Im of frames
+    // 0..31 in the two lane halves of one register (the A operand of row tile 0) and frames 32..63 in the other.
+    // MT == 1: a lane loads the one float it feeds to the MFMA.
+    const float* xa = nullptr;
+    const float2* bp = nullptr;   // column pairs
+    float2 av[BD_NS][BD_KU], bv[BD_NS][BD_KU / 2];
+    auto fetch = [&](int s, int c) {
+#pragma unroll
+        for (int u = 0; u < BD_KU / 2; ++u) bv[s][u] = bp[(size_t)(c / 2 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < BD_KU; ++u) {
+            if (MT == 2)
+                av[s][u] = *reinterpret_cast<const float2*>(xa + (size_t)(c + u) * col_stride);
+            else
+                av[s][u].x = xa[(size_t)(c + u) * col_stride];
+        }
+    };
+    // point the operand streams at a block and put its first BD_NS - 1 stages in flight
+    auto open_block = [&](const BandBlock& blk) {
+        xa = MT == 2 ? a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + lane) * 2
+                     : a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + n) * 2 + kx;
+        bp = reinterpret_cast<const float2*>(a.B) + (size_t)blk.boff * 32 + lane;
+#pragma unroll
+        for (int s = 0; s < BD_NS - 1; ++s) fetch(s, s * BD_KU);
+    };
+    BandBlock blk{};
+    if (n_blocks > 0) {
+        blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave])];
+        open_block(blk);
+    }
     for (int bi = 0; bi < n_blocks; ++bi) {
-        const BandBlock blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi])];
-        // MT == 2: a lane loads (Re, Im) of one of 64 frames; a half swap then leaves Re of frames 0..31 / Im of
-        // frames 0..31 in the two lane halves of one register (the A operand of row tile 0) and frames 32..63 in
-        // the other.  MT == 1: a lane loads the one float it feeds to the MFMA.
-        const float* xa = MT == 2 ? a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + lane) * 2
-                                  : a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + n) * 2 + kx;
-        const float2* bp = reinterpret_cast<const float2*>(a.B) + (size_t)blk.boff * 32 + lane;   // column pairs
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
-        float2 av[BD_NS][BD_KU], bv[BD_NS][BD_KU / 2];
-        auto fetch = [&](int s, int c) {
-#pragma unroll
-            for (int u = 0; u < BD_KU / 2; ++u) bv[s][u] = bp[(size_t)(c / 2 + u) * 64];
-#pragma unroll
-            for (int u = 0; u < BD_KU; ++u) {
-                if (MT == 2)
-                    av[s][u] = *reinterpret_cast<const float2*>(xa + (size_t)(c + u) * col_stride);
-                else
-                    av[s][u].x = xa[(size_t)(c + u) * col_stride];
-            }
-        };
         auto mul = [&](int s) {
 #pragma unroll
             for (int u = 0; u < BD_KU; ++u) {
@@ -721,8 +732,6 @@ __global__ __launch_bounds__(256) void blockdft_banddots_db(BandArgs a) {
         // ring of BD_NS stages of BD_KU columns: BD_NS - 1 stages of operands in flight while one is multiplied.
         // kb is a multiple of BD_KU; the fetches run up to (BD_NS - 1) * BD_KU columns past the block (in bounds
         // by construction, never multiplied).
-#pragma unroll
-        for (int s = 0; s < BD_NS - 1; ++s) fetch(s, s * BD_KU);
         const int kb = __builtin_amdgcn_readfirstlane(blk.kb);
         const int kb_full = kb - kb % (BD_NS * BD_KU);
         int c = 0;
@@ -731,39 +740,46 @@ __global__ __launch_bounds__(256) void blockdft_banddots_db(BandArgs a) {
             for (int s = 0; s < BD_NS; ++s) {
                 fetch((s + BD_NS - 1) % BD_NS, c + (s + BD_NS - 1) * BD_KU);
                 mul(s);
+                // keep a stage's lane swaps (and the waits on its operands) inside the stage: the scheduler would
+                // otherwise hoist the swaps of later stages to the top and wait for the whole ring
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int s = 0; s < BD_NS - 1; ++s)         // remainder: the operands are already in flight
             if (c + s * BD_KU < kb) mul(s);
+        // the next block's first operands fly while this block's results are written out
+        const int bin0 = blk.bin0, nrows = blk.nrows;
+        if (bi + 1 < n_blocks) {
+            blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi + 1])];
+            open_block(blk);
+        }
         // C layout: column n = lane & 31 (bin row = n & 15, re / im = n >> 4), frame = (q&3) + 8(q>>2) + 4(lane>>5).
         // v_permlane16_swap brings the im column's value into the re column's lane.
-        float im[MT][16];
+        const bool mine = part == 0 && row < nrows;
+        const int bin = bin0 + row;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            float im[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 float re = acc[mt][q], o = 0.0f;
                 permlane16_swap(re, o);   // o: rows 0 / 2 now hold the im columns' values
-                im[mt][q] = o;
+                im[q] = o;
             }
-        if (part == 0 && row < blk.nrows) {
-            const int bin = blk.bin0 + row;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            if (mine) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                    dbs[fr * a.ldb + bin] = acc[mt][q] * acc[mt][q] + im[mt][q] * im[mt][q];
+                    dbs[fr * a.ldb + bin] = acc[mt][q] * acc[mt][q] + im[q] * im[q];
                 }
-            if (a.out_cplx) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                if (a.out_cplx) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                        if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * a.n_bins + bin] = make_float2(acc[mt][q], im[mt][q]);
+                        if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * a.n_bins + bin] = make_float2(acc[mt][q], im[q]);
                     }
+                }
             }
         }
     }
@@ -774,7 +790,8 @@ __global__ __launch_bounds__(256) void blockdft_banddots_db(BandArgs a) {
         float* rowp = dbs + fr * a.ldb;
         float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
         for (int k = lane; k < a.n_bins; k += 64) {
-            const float d = 10.0f * log10f(fmaxf(rowp[k], PVQ_A_MIN)) - ref_db;
+            // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
+            const float d = 3.01029995663981f * __log2f(fmaxf(rowp[k], PVQ_A_MIN)) - ref_db;
             rowp[k] = d;
             mx = fmaxf(mx, d);
             mn = fminf(mn, d);
