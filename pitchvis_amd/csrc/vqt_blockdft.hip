@@ -42,8 +42,8 @@ constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
 static size_t chunk_frames() {  // frames per sub-batch: P and X of one chunk should stay in the Infinity Cache
     const char* e = getenv("PVQ_CHUNK_FRAMES");  // developer knob
-    const long v = e ? atol(e) : 32768;
-    return (size_t)(v >= 64 ? v : 32768);
+    const long v = e ? atol(e) : 65536;
+    return (size_t)(v >= 64 ? v : 65536);
 }
 
 struct BlockGroup {
