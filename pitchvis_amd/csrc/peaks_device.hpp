@@ -319,6 +319,12 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
 // ------------------------------------------------------------------------------------------------
 constexpr int PK_PAD = 16;
 
+// LDS scratch of the lean routine besides the frame: candidate list (u16), peak list (u16), peak flags (u8)
+__host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins) {
+    const size_t n = (size_t)((n_bins + 63) / 64 * 64);
+    return 3 * n;
+}
+
 template <int NK>
 __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
                                                 int lane) {
@@ -326,7 +332,9 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     const int npad = (n + 63) / 64 * 64;
     const int words = (n + 31) / 32;
     const float INF = __builtin_huge_valf();
-    uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);
+    uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
+    uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);   // peaks, ascending
+    uint8_t* flag = scratch + 2 * npad;                              // flag[bin] = 1 for a peak
     float v[NK];
     float fmin_ = INF;
     bool plateau = false;
@@ -337,12 +345,15 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         if (i < n) fmin_ = fminf(fmin_, v[k]);
         // a rise followed by an equal sample may start a plateau peak: leave those frames to the generic code
         plateau |= (i >= 1 && i < n - 1) && (x[i - 1] < v[k]) && (x[i + 1] == v[k]);
+        if (i < npad) flag[i] = 0;
     }
     if (__ballot(plateau)) return false;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
 
-    uint32_t total = 0;
+    // 1. candidates of the whole frame, compacted: the window walk below then runs once per 64 candidates
+    //    instead of once per 64 bins (a third of the bins are local maxima, far fewer pass height / range)
+    uint32_t n_cand = 0;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         if ((k << 6) >= n) break;
@@ -353,44 +364,65 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
         const bool pre = (i >= a.min_bin) && (i < n) && (x[i - 1] < xv) && (x[i + 1] < xv) && (xv >= H) &&
                          (!(P > 0.0f) || (xv - fmin_ >= P));
-        unsigned long long pm = 0ull;
-        if (__ballot(pre)) {
-            float ML = -INF, mL = INF, MR = -INF, mR = INF;
+        const unsigned long long bm = __ballot(pre);
+        if (pre) clist[n_cand + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        n_cand += __popcll(bm);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // 2. prominence of each candidate over a PK_PAD-sample window on both sides
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < n_cand; base += 64) {
+        const bool have = base + lane < n_cand;
+        const int i = have ? (int)clist[base + lane] : a.min_bin;
+        const float xv = x[i];
+        const float P = (i <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
+        // pL / pR: a sample higher than the peak has been met on that side (later samples no longer count)
+        bool pL = false, pR = false;
+        float mL = INF, mR = INF;
 #pragma unroll
-            for (int s = 1; s <= PK_PAD; ++s) {
-                const float vl = x[i - s], vr = x[i + s];
-                ML = fmaxf(ML, vl);
-                MR = fmaxf(MR, vr);
-                mL = fminf(mL, (ML > xv) ? INF : vl);
-                mR = fminf(mR, (MR > xv) ? INF : vr);
-            }
-            const bool noP = !(P > 0.0f);
-            const bool okL = noP || (xv - mL >= P), okR = noP || (xv - mR >= P);
-            const bool failed = (!okL && ML > xv) || (!okR && MR > xv);
-            const bool peak = pre && okL && okR;
-            pm = __ballot(peak);
-            unsigned long long cm = __ballot(pre && !peak && !failed);  // window too short: exact test
-            while (cm) {
-                const int b = __builtin_ctzll(cm);
-                cm &= cm - 1;
-                const int ci = (k << 6) + b;
-                const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b));
-                const float Pc = (ci <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
-                if (pk_prom_ok_wave<NK>(v, n, ci, h, Pc, lane)) pm |= 1ull << b;
-            }
+        for (int s = 1; s <= PK_PAD; ++s) {
+            const float vl = x[i - s], vr = x[i + s];
+            pL |= vl > xv;
+            pR |= vr > xv;
+            mL = fminf(mL, pL ? INF : vl);
+            mR = fminf(mR, pR ? INF : vr);
         }
-        if (a.mask) {
+        const bool noP = !(P > 0.0f);
+        const bool okL = noP || (xv - mL >= P), okR = noP || (xv - mR >= P);
+        const bool failed = (!okL && pL) || (!okR && pR);
+        bool peak = have && okL && okR;
+        unsigned long long cm = __ballot(have && !peak && !failed);  // window too short: exact test
+        while (cm) {
+            const int b = __builtin_ctzll(cm);
+            cm &= cm - 1;
+            const int ci = __builtin_amdgcn_readlane(i, b);
+            const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b));
+            const float Pc = (ci <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
+            const bool ok = pk_prom_ok_wave<NK>(v, n, ci, h, Pc, lane);
+            if (lane == b) peak = ok;
+        }
+        const unsigned long long pm = __ballot(peak);
+        if (peak) {
+            plist[total + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            flag[i] = 1;
+        }
+        total += __popcll(pm);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (a.mask) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if ((k << 6) >= n) break;
+            const unsigned long long pm = __ballot(flag[(k << 6) + lane] != 0);
             if (lane == 0 && 2 * k < words) a.mask[frame * words + 2 * k] = (uint32_t)pm;
             if (lane == 1 && 2 * k + 1 < words) a.mask[frame * words + 2 * k + 1] = (uint32_t)(pm >> 32);
         }
-        const uint32_t slot = total + __popcll(pm & ((1ull << lane) - 1ull));
-        total += __popcll(pm);
-        if ((pm >> lane) & 1ull) plist[slot] = (uint16_t)i;
     }
     if (a.count && lane == 0) a.count[frame] = total;
     if (a.center) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         const uint32_t lim = total < a.max_peaks ? total : a.max_peaks;
         for (uint32_t sidx = lane; sidx < lim; sidx += 64) {
             float ctr, sz;

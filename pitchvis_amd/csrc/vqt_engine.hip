@@ -353,7 +353,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames_lean(const floa
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
-    const size_t per_wave = sizeof(float) * (npad + 2 * PK_PAD) + peaks_scratch_bytes(n, 1);
+    const size_t per_wave = sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(n);
     float* xs = reinterpret_cast<float*>(pk_smem + wv * per_wave);
     float* x = xs + PK_PAD;  // x[-PK_PAD..-1] and x[n..npad+PK_PAD-1] hold +INF sentinels
     unsigned char* scratch = reinterpret_cast<unsigned char*>(xs + npad + 2 * PK_PAD);
@@ -699,7 +699,7 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
     if (st != PVQ_OK) return st;
     uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
-    const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_scratch_bytes(a.n_bins, 1));
+    const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(a.n_bins));
     if (a.n_bins <= 256) {
         hipLaunchKernelGGL(peaks_frames_lean<4>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
         hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(std::min(grid, 512)), dim3(PK_WAVES * 64), lds_gen, stream, d_db,

@@ -25,6 +25,9 @@ def run(name, fn, n=10):
     print(f"{name:28s} {dt*1e3:7.3f} ms/step  {nf/dt/1e6:6.2f} Mf/s  " + "  ".join(f"{k}={km[k]*1e3:.1f}us x{kn[k]//n}" for k in km))
 run("vqt only", lambda: v.calculate_batch_db_device(d_pcm, hop, nf, d_db))
 if "once" in sys.argv: sys.exit(0)
+if "withpeaks" in sys.argv:
+    run("vqt + mask/count/continuous", lambda: v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt, d_c, d_s, 64), n=3)
+    sys.exit(0)
 run("vqt + mask/count", lambda: v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt))
 run("vqt + mask/count/continuous", lambda: v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt, d_c, d_s, 64))
 run("standalone peaks full", lambda: v.analyze_batch_device(d_db, nf, d_mask, d_cnt, d_c, d_s, 64))
