@@ -287,23 +287,62 @@ __device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
 // below is bank-conflict free), then the store of the S complete frames, column-major
 constexpr int FT_LDP = CB_C + 1;                      // P tile row stride in complex elements
 constexpr int FT_P_FLOATS = FT_BM * FT_LDP * 2;       // 33 792 B
-__device__ __forceinline__ void fused_tree_store(float* smem, const FusedTile& t, const GemmTreeArgs& a, int tid) {
+// the tile's combine twiddles (levels x 32 columns) into LDS, issued before the K loop so the tree never waits on memory
+constexpr int FT_MAXL = 6;
+__device__ __forceinline__ void fused_stage_twiddles(float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid) {
+    const int l = tid >> 5, c = tid & (CB_C - 1);
+    if (l < t.G.levels) tw[l][c] = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
+}
+
+__device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid) {
     float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);  // [128][33]
     const int c = tid & (CB_C - 1);
     constexpr int PER = FT_BM * CB_C / 256;  // 16
+    auto cmadd = [](float2 lo, float2 w, float2 hi) {   // lo + w * hi
+        return make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
+    };
+    const int levels = t.G.levels;
     int valid = FT_BM;
-    for (int l = 0; l < t.G.levels; ++l) {
+    int l = 0;
+    {
+        // two levels per pass, evaluated exactly as two radix-2 levels (same operations in the same order), without the
+        // round trip of the intermediate level through LDS; outputs in groups of four to bound the registers
+        for (; l + 1 < levels; l += 2) {
+            const int st = 1 << l;
+            const float2 w1 = tw[l][c], w2 = tw[l + 1][c];
+            valid -= 3 * st;
+            float2 v[PER];
+#pragma unroll
+            for (int g = 0; g < PER; g += 4) {
+#pragma unroll
+                for (int q = g; q < g + 4; ++q) {
+                    const int j = (tid + q * 256) / CB_C;
+                    if (j < valid) {
+                        const float2 t0 = cmadd(A[j][c], w1, A[j + st][c]);
+                        const float2 t1 = cmadd(A[j + 2 * st][c], w1, A[j + 3 * st][c]);
+                        v[q] = cmadd(t0, w2, t1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int j = (tid + q * 256) / CB_C;
+                if (j < valid) A[j][c] = v[q];
+            }
+            __syncthreads();
+        }
+    }
+    for (; l < levels; ++l) {
         const int st = 1 << l;
         valid -= st;
-        const float2 w = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
+        const float2 w = tw[l][c];
         float2 v[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int j = (tid + q * 256) / CB_C;
-            if (j < valid) {
-                const float2 lo = A[j][c], hi = A[j + st][c];
-                v[q] = make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
-            }
+            if (j < valid) v[q] = cmadd(A[j][c], w, A[j + st][c]);
         }
         __syncthreads();
 #pragma unroll
@@ -325,6 +364,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const FusedTile& t
 
 __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FT_P_FLOATS];  // 33 KB: staging buffers, then the P tile
+    __shared__ float2 tw_lds[FT_MAXL][CB_C];
     float (*As)[FT_BM][FT_BK + 1] = reinterpret_cast<float (*)[FT_BM][FT_BK + 1]>(smem);                       // [2][128][17]
     float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * FT_BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,6 +372,7 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
     const BlockGroup& G = T.G;
     const int f0 = T.f0, nt = T.nt;
     if (f0 >= a.n_frames) return;
+    fused_stage_twiddles(tw_lds, T, a, tid);
     const int wm = wave >> 1, wn = wave & 1;
     const long long s = a.base + G.s_rel;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
@@ -392,7 +433,7 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
         smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
     }
     __syncthreads();
-    fused_tree_store(smem, T, a, tid);
+    fused_tree_store(smem, tw_lds, T, a, tid);
 }
 
 // Split-bf16 form of the fused kernel ("bf16x3", the default; pvq_vqt_set_gemm_precision): same tile, same
@@ -508,11 +549,13 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
 
 __global__ __launch_bounds__(256) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[FB_LDS_BYTES];
+    __shared__ float2 tw_lds[FT_MAXL][CB_C];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FusedTile T = fused_tile(a);
     const int f0 = T.f0, nt = T.nt;
     if (f0 >= a.n_frames) return;
+    fused_stage_twiddles(tw_lds, T, a, tid);
     const int wm = wave >> 1, wn = wave & 1;
     const long long s = a.base + T.G.s_rel;
     const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)FT_BM * a.K;  // sample range of the tile
@@ -536,7 +579,7 @@ __global__ __launch_bounds__(256) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a)
         smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
     }
     __syncthreads();
-    fused_tree_store(smem, T, a, tid);
+    fused_tree_store(smem, tw_lds, T, a, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
