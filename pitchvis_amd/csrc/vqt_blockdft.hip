@@ -63,11 +63,13 @@ struct BandBlock {
     int boff;    // first column of this block in d_band_B (units of 64 floats)
     int bin0;    // first output bin
     int nrows;   // 1..16
+    int kg;      // 8-column groups walked by the split-bf16 form
+    int boff3;   // first group of this block in d_band_B3 (units of 3 planes x 64 lanes x 8 bf16)
 };
 constexpr int BD_RB = 16;   // bins per block: 32 MFMA columns = 16 x (re, im)
 constexpr int BD_KU = 4;    // columns per software-pipeline stage
 constexpr int BD_NS = 4;    // pipeline stages
-constexpr int X_PAD_COLS = BD_NS * BD_KU;   // zeroed columns after the last X column (prefetch runs past a block's range)
+constexpr int X_PAD_COLS = 32;   // zeroed columns after the last X column (the operand prefetch runs past a block's range)
 
 struct BlockDftTables {
     size_t hop = 0;
@@ -86,6 +88,7 @@ struct BlockDftTables {
     // banded kernel product: blocks of 16 output bins x their union of spectrum columns, as MFMA B operands
     struct BandBlock* d_band = nullptr;
     float* d_band_B = nullptr;     // per block and column: 64 floats in v_mfma_f32_32x32x2_f32 B-operand lane order
+    __bf16* d_band_B3 = nullptr;   // per block and 8 columns: 3 planes x 64 lanes x 8 bf16 in v_mfma_f32_32x32x16_bf16 order
     int* d_band_list = nullptr;    // [4][band_per_wave]: the blocks each wave of a workgroup walks
     int band_per_wave = 0;
     int band_cnt[4] = {0, 0, 0, 0};
@@ -103,6 +106,7 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_comb_tw) (void)hipFree(t->d_comb_tw);
     if (t->d_band) (void)hipFree(t->d_band);
     if (t->d_band_B) (void)hipFree(t->d_band_B);
+    if (t->d_band_B3) (void)hipFree(t->d_band_B3);
     if (t->d_band_list) (void)hipFree(t->d_band_list);
     if (t->d_P) (void)hipFree(t->d_P);
     if (t->d_X) (void)hipFree(t->d_X);
@@ -673,6 +677,7 @@ struct BandArgs {
     int ldb;                   // LDS row stride of the dB tile
     const BandBlock* blocks;
     const float* B;
+    const __bf16* B3;          // split-bf16 coefficient planes
     const int* list;           // [4][per_wave]
     int per_wave;
     int cnt[4];
@@ -712,14 +717,75 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 
+// results of one block (C layout: column n = lane & 31: bin row = n & 15, re / im = n >> 4; frame =
+// (q&3) + 8(q>>2) + 4(lane>>5)) -> |x_vqt|^2 into the LDS tile (+ the optional complex output).
+// v_permlane16_swap brings the im column's value into the re column's lane.
+template <int MT>
+__device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, int f0, int bin0, int nrows,
+                                              int lane) {
+    const int n = lane & 31, kx = lane >> 5;
+    const int row = n & 15, part = n >> 4;
+    const bool mine = part == 0 && row < nrows;
+    const int bin = bin0 + row;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float im[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float re = acc[mt][q], o = 0.0f;
+            permlane16_swap(re, o);   // o: rows 0 / 2 now hold the im columns' values
+            im[q] = o;
+        }
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
+                dbs[fr * a.ldb + bin] = acc[mt][q] * acc[mt][q] + im[q] * im[q];
+            }
+            if (a.out_cplx) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
+                    if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * a.n_bins + bin] = make_float2(acc[mt][q], im[q]);
+                }
+            }
+        }
+    }
+}
+
+// power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins
+template <int MT>
+__device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f0, int wave, int lane) {
+    const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
+    for (int fr = wave; fr < MT * 32; fr += 4) {
+        if (f0 + fr >= a.n_frames) break;
+        float* rowp = dbs + fr * a.ldb;
+        float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
+        for (int k = lane; k < a.n_bins; k += 64) {
+            // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
+            const float d = 3.01029995663981f * __log2f(fmaxf(rowp[k], PVQ_A_MIN)) - ref_db;
+            rowp[k] = d;
+            mx = fmaxf(mx, d);
+            mn = fminf(mn, d);
+        }
+        mx = wave_max(mx);
+        mn = wave_min(mn);
+        const float floor_db = mx - PVQ_TOP_DB;
+        const float m2 = fmaxf(mn, floor_db);
+        float* dst = a.out_db + (size_t)(f0 + fr) * a.n_bins;
+        for (int k = lane; k < a.n_bins; k += 64) {
+            const float c = fmaxf(rowp[k], floor_db);
+            dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
+        }
+    }
+}
+
 template <int MT>   // 32-frame MFMA row tiles per workgroup
 __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
     const int n = lane & 31, kx = lane >> 5;
-    const int row = n & 15, part = n >> 4;
-    const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     const size_t col_stride = (size_t)a.ldf * 2;   // floats between consecutive X columns
     const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
     // MT == 2: a lane loads (Re, Im) of one of 64 frames; a half swap then leaves Re of frames 0..31 / Im of frames
@@ -797,63 +863,126 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
             blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi + 1])];
             open_block(blk);
         }
-        // C layout: column n = lane & 31 (bin row = n & 15, re / im = n >> 4), frame = (q&3) + 8(q>>2) + 4(lane>>5).
-        // v_permlane16_swap brings the im column's value into the re column's lane.
-        const bool mine = part == 0 && row < nrows;
-        const int bin = bin0 + row;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            float im[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float re = acc[mt][q], o = 0.0f;
-                permlane16_swap(re, o);   // o: rows 0 / 2 now hold the im columns' values
-                im[q] = o;
-            }
-            if (mine) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                    dbs[fr * a.ldb + bin] = acc[mt][q] * acc[mt][q] + im[q] * im[q];
-                }
-                if (a.out_cplx) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                        if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * a.n_bins + bin] = make_float2(acc[mt][q], im[q]);
-                    }
-                }
-            }
-        }
+        band_writeout<MT>(acc, dbs, a, f0, bin0, nrows, lane);
     }
     __syncthreads();
-    // power_to_db per frame: a wave per frame, lanes over bins
-    for (int fr = wave; fr < MT * 32; fr += 4) {
-        if (f0 + fr >= a.n_frames) break;
-        float* rowp = dbs + fr * a.ldb;
-        float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
-        for (int k = lane; k < a.n_bins; k += 64) {
-            // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
-            const float d = 3.01029995663981f * __log2f(fmaxf(rowp[k], PVQ_A_MIN)) - ref_db;
-            rowp[k] = d;
-            mx = fmaxf(mx, d);
-            mn = fminf(mn, d);
-        }
-        mx = wave_max(mx);
-        mn = wave_min(mn);
-        const float floor_db = mx - PVQ_TOP_DB;
-        const float m2 = fmaxf(mn, floor_db);
-        float* dst = a.out_db + (size_t)(f0 + fr) * a.n_bins;
-        for (int k = lane; k < a.n_bins; k += 64) {
-            const float c = fmaxf(rowp[k], floor_db);
-            dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
-        }
+    band_finish<MT>(dbs, a, f0, wave, lane);
+}
+
+// Split-bf16 form of the kernel product (the default, with the split-bf16 GEMM): the fp32 MFMA above runs at 1/16
+// of the bf16 matrix rate, and a 16-bin block is 73 % zeros, so the stage is matrix-bound.  Here X and the
+// coefficients are written as hi + mid + lo bf16 (exact 3-way split, see blockdft_gemm_tree_bf16x3) and eight
+// spectrum columns (16 real k) go through six v_mfma_f32_32x32x16_bf16: 6 x 32 cycles instead of 8 x 64.  A lane
+// (frame m, half kh) loads (Re, Im) of columns 4 kh .. 4 kh + 3 of its frame — the same bytes per lane as the fp32
+// form — and splits them in registers; the coefficient planes come pre-split in B-operand order.
+constexpr int B3_NS = 3;   // 8-column stages in flight
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void blockdft_banddots_db_bf16x3(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = blockIdx.x * (MT * 32);
+    const int n = lane & 31, kx = lane >> 5;
+    const size_t col_stride = (size_t)a.ldf * 2;   // floats between consecutive X columns
+    const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
+    const float* xa = nullptr;
+    const bf16x8* bp = nullptr;
+    float2 av[B3_NS][MT][4];
+    bf16x8 bv[B3_NS][3];
+    auto fetch = [&](int s, int g) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bv[s][p] = bp[((size_t)g * 3 + p) * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[s][mt][q] = *reinterpret_cast<const float2*>(xa + (size_t)(8 * g + q) * col_stride + mt * 64);
+    };
+    auto open_block = [&](const BandBlock& blk) {
+        xa = a.X + (size_t)(blk.x0 + 4 * kx) * col_stride + (size_t)(f0 + n) * 2;
+        bp = reinterpret_cast<const bf16x8*>(a.B3) + (size_t)blk.boff3 * 3 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < B3_NS - 1; ++s) fetch(s, s);
+    };
+    BandBlock blk{};
+    if (n_blocks > 0) {
+        blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave])];
+        open_block(blk);
     }
+    for (int bi = 0; bi < n_blocks; ++bi) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
+        auto mul = [&](int s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x8 vh, vm, vl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        const float x = part ? av[s][mt][q].y : av[s][mt][q].x;
+                        const __bf16 hi = (__bf16)x;
+                        const float r1 = x - (float)hi;
+                        const __bf16 mid = (__bf16)r1;
+                        vh[2 * q + part] = hi;
+                        vm[2 * q + part] = mid;
+                        vl[2 * q + part] = (__bf16)(r1 - (float)mid);
+                    }
+                }
+                // smallest terms first
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, bv[s][1], acc[mt], 0, 0, 0);  // mid*mid
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bv[s][2], acc[mt], 0, 0, 0);  // hi*lo
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, bv[s][0], acc[mt], 0, 0, 0);  // lo*hi
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bv[s][1], acc[mt], 0, 0, 0);  // hi*mid
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, bv[s][0], acc[mt], 0, 0, 0);  // mid*hi
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bv[s][0], acc[mt], 0, 0, 0);  // hi*hi
+            }
+        };
+        const int kg = __builtin_amdgcn_readfirstlane(blk.kg);
+        const int kg_full = kg - kg % B3_NS;
+        int g = 0;
+        for (; g < kg_full; g += B3_NS) {   // steady state: no branches, exact load counting
+#pragma unroll
+            for (int s = 0; s < B3_NS; ++s) {
+                fetch((s + B3_NS - 1) % B3_NS, g + s + B3_NS - 1);
+                mul(s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < B3_NS - 1; ++s)         // remainder: the operands are already in flight
+            if (g + s < kg) mul(s);
+        // the next block's first operands fly while this block's results are written out
+        const int bin0 = blk.bin0, nrows = blk.nrows;
+        if (bi + 1 < n_blocks) {
+            blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi + 1])];
+            open_block(blk);
+        }
+        band_writeout<MT>(acc, dbs, a, f0, bin0, nrows, lane);
+    }
+    __syncthreads();
+    band_finish<MT>(dbs, a, f0, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// round-to-nearest-even bf16 of a finite float (host)
+static inline uint16_t host_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float host_from_bf16(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_t)(dev_->block->n_tiles * CB_C) : 0u; }
 
 bool Vqt::blockdft_applicable(size_t hop) const {
@@ -1006,6 +1135,30 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         }
     }
     band_B.resize(band_B.size() + (size_t)BD_NS * BD_KU * 64, 0.0f);   // the prefetch of the last block runs on past it
+    // split-bf16 planes of the same coefficients, 8 columns (16 real k) per MFMA: lane (n = l & 31, kh = l >> 5)
+    // holds k = 8 kh + t, t = 0..7  <->  column 4 kh + t / 2, Re / Im row t & 1
+    std::vector<uint16_t> band_B3;
+    for (BandBlock& bb : band) {
+        bb.kg = (bb.kb + 7) / 8;
+        bb.boff3 = (int)(band_B3.size() / (3 * 64 * 8));
+        band_B3.resize(band_B3.size() + (size_t)bb.kg * 3 * 64 * 8, 0);
+        float* Bp = band_B.data() + (size_t)bb.boff * 64;
+        for (int g = 0; g < bb.kg; ++g)
+            for (int l = 0; l < 64; ++l)
+                for (int tt = 0; tt < 8; ++tt) {
+                    const int col = 8 * g + 4 * (l >> 5) + (tt >> 1);
+                    const float x = col < bb.kb ? at(Bp, col, (tt & 1) * 32 + (l & 31)) : 0.0f;
+                    const uint16_t h = host_to_bf16(x);
+                    const float r1 = x - host_from_bf16(h);
+                    const uint16_t m = host_to_bf16(r1);
+                    const uint16_t lo = host_to_bf16(r1 - host_from_bf16(m));
+                    const size_t base = ((size_t)(bb.boff3 + g) * 3) * 64 * 8 + (size_t)l * 8 + tt;
+                    band_B3[base] = h;
+                    band_B3[base + 64 * 8] = m;
+                    band_B3[base + 2 * 64 * 8] = lo;
+                }
+    }
+    band_B3.resize(band_B3.size() + (size_t)B3_NS * 3 * 64 * 8, 0);
     // blocks to waves: round robin in bin order, so that the four waves of a workgroup walk neighbouring blocks
     // (whose column ranges overlap) at the same time and share the X columns through L1 / L2
     std::vector<std::vector<int>> per_wave(4);
@@ -1027,7 +1180,8 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
     t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
-              up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list);
+              up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) &&
+              up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3);
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -1074,28 +1228,16 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     const long long n_samples = (long long)(n_lead + n_frames * hop);
     if (use_bf && fused && !t->d_Et) {
         // bf16 split of E^T (round-to-nearest-even on the bit patterns), built on first use
-        auto to_bf16 = [](float f) -> uint16_t {
-            uint32_t u;
-            std::memcpy(&u, &f, 4);
-            u += 0x7fffu + ((u >> 16) & 1u);   // E holds finite values in [-1, 1]
-            return (uint16_t)(u >> 16);
-        };
-        auto from_bf16 = [](uint16_t h) -> float {
-            uint32_t u = (uint32_t)h << 16;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
         std::vector<uint16_t> Et((size_t)3 * ntot * hop);
         for (int n = 0; n < ntot; ++n)
             for (size_t m = 0; m < hop; ++m) {
                 const float x = t->h_E[m * ntot + n];
-                const uint16_t h = to_bf16(x);
-                const float r1 = x - from_bf16(h);
-                const uint16_t mid = to_bf16(r1);
+                const uint16_t h = host_to_bf16(x);
+                const float r1 = x - host_from_bf16(h);
+                const uint16_t mid = host_to_bf16(r1);
                 Et[((size_t)0 * ntot + n) * hop + m] = h;
                 Et[((size_t)1 * ntot + n) * hop + m] = mid;
-                Et[((size_t)2 * ntot + n) * hop + m] = to_bf16(r1 - from_bf16(mid));
+                Et[((size_t)2 * ntot + n) * hop + m] = host_to_bf16(r1 - host_from_bf16(mid));
             }
         PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_Et), Et.size() * 2));
         PVQ_HIP(hipMemcpy(t->d_Et, Et.data(), Et.size() * 2, hipMemcpyHostToDevice));
@@ -1189,6 +1331,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.ldb = t->n_bins_pad + 4;   // 4 rows apart (the two lane halves of a C tile) land 16 banks apart
         da.blocks = t->d_band;
         da.B = t->d_band_B;
+        da.B3 = t->d_band_B3;
         da.list = t->d_band_list;
         da.per_wave = t->band_per_wave;
         for (int w = 0; w < 4; ++w) da.cnt[w] = t->band_cnt[w];
@@ -1197,12 +1340,20 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
         static const int mt_env = getenv("PVQ_DOTS_MT") ? atoi(getenv("PVQ_DOTS_MT")) : 0;   // developer knob
         const int mt = mt_env ? mt_env : (t->n_bins_pad <= 256 ? 2 : 1);
+        static const int dots_f32_env = getenv("PVQ_DOTS_F32") ? atoi(getenv("PVQ_DOTS_F32")) : 0;   // developer knob
+        const bool dots_split = gemm_split_bf16_ && !dots_f32_env;   // the kernel product follows the GEMM arithmetic
+        const size_t lds = sizeof(float) * 32 * mt * da.ldb;
+        const dim3 grid((unsigned)((nf + 32 * mt - 1) / (32 * mt)));
         if (mt == 2) {
-            const size_t lds = sizeof(float) * 64 * da.ldb;
-            hipLaunchKernelGGL(blockdft_banddots_db<2>, dim3((unsigned)((nf + 63) / 64)), dim3(256), lds, stream, da);
+            if (dots_split)
+                hipLaunchKernelGGL(blockdft_banddots_db_bf16x3<2>, grid, dim3(256), lds, stream, da);
+            else
+                hipLaunchKernelGGL(blockdft_banddots_db<2>, grid, dim3(256), lds, stream, da);
         } else {
-            const size_t lds = sizeof(float) * 32 * da.ldb;
-            hipLaunchKernelGGL(blockdft_banddots_db<1>, dim3((unsigned)((nf + 31) / 32)), dim3(256), lds, stream, da);
+            if (dots_split)
+                hipLaunchKernelGGL(blockdft_banddots_db_bf16x3<1>, grid, dim3(256), lds, stream, da);
+            else
+                hipLaunchKernelGGL(blockdft_banddots_db<1>, grid, dim3(256), lds, stream, da);
         }
         slot_end(SLOT_BLOCKDFT_DOTS, stream);
     }
