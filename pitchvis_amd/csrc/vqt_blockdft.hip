@@ -298,45 +298,84 @@ __device__ __forceinline__ void fused_stage_twiddles(float2 (*tw)[CB_C], const F
     if (l < t.G.levels) tw[l][c] = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
 }
 
+// lo + w * hi with a fixed operation order (explicit fma, no further contraction): every tree level, whichever code
+// path evaluates it, rounds identically, so a frame's result does not depend on where it sits in a tile
+__device__ __forceinline__ float2 tree_cmadd(float2 lo, float2 w, float2 hi) {
+#pragma clang fp contract(off)
+    const float re = __builtin_fmaf(-w.y, hi.y, w.x * hi.x);
+    const float im = __builtin_fmaf(w.y, hi.x, w.x * hi.y);
+    return make_float2(lo.x + re, lo.y + im);
+}
+
+// the first R <= 4 tree levels (strides 1 .. 8) in registers: a thread owns 16 consecutive rows of one column and
+// reads them plus the 2^R - 1 rows above once; every A_{l+1}[j] = A_l[j] + w_l A_l[j + 2^l] is evaluated exactly as
+// the level-by-level form would, without a pass through LDS per level.  Rows past the tile read as zero: they only
+// feed outputs that are themselves incomplete.
+template <int R>
+__device__ __forceinline__ void fused_tree_register_levels(float2 (*A)[CB_C + 1], const float2 (*tw)[CB_C], int tid) {
+    constexpr int H = (1 << R) - 1;
+    const int c = tid & (CB_C - 1), j0 = (tid >> 5) * 16;
+    float2 v[16 + H];
+#pragma unroll
+    for (int i = 0; i < 16 + H; ++i) v[i] = (j0 + i < FT_BM) ? A[j0 + i][c] : make_float2(0.0f, 0.0f);
+    int len = 16 + H;
+#pragma unroll
+    for (int l = 0; l < R; ++l) {
+        const int st = 1 << l;
+        const float2 w = tw[l][c];
+        len -= st;
+#pragma unroll
+        for (int i = 0; i < 16 + H; ++i)
+            if (i < len) v[i] = tree_cmadd(v[i], w, v[i + st]);
+    }
+    __syncthreads();   // every thread has read its halo
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A[j0 + i][c] = v[i];
+    __syncthreads();
+}
+
 __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid) {
     float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);  // [128][33]
     const int c = tid & (CB_C - 1);
     constexpr int PER = FT_BM * CB_C / 256;  // 16
-    auto cmadd = [](float2 lo, float2 w, float2 hi) {   // lo + w * hi
-        return make_float2(lo.x + (w.x * hi.x - w.y * hi.y), lo.y + (w.x * hi.y + w.y * hi.x));
-    };
+    auto cmadd = [](float2 lo, float2 w, float2 hi) { return tree_cmadd(lo, w, hi); };
     const int levels = t.G.levels;
-    int valid = FT_BM;
-    int l = 0;
-    {
-        // two levels per pass, evaluated exactly as two radix-2 levels (same operations in the same order), without the
-        // round trip of the intermediate level through LDS; outputs in groups of four to bound the registers
-        for (; l + 1 < levels; l += 2) {
-            const int st = 1 << l;
-            const float2 w1 = tw[l][c], w2 = tw[l + 1][c];
-            valid -= 3 * st;
-            float2 v[PER];
+    int l = levels < 4 ? levels : 4;
+    switch (l) {   // wave-uniform
+        case 1: fused_tree_register_levels<1>(A, tw, tid); break;
+        case 2: fused_tree_register_levels<2>(A, tw, tid); break;
+        case 3: fused_tree_register_levels<3>(A, tw, tid); break;
+        case 4: fused_tree_register_levels<4>(A, tw, tid); break;
+        default: break;
+    }
+    int valid = FT_BM - ((1 << l) - 1);
+    // remaining levels (strides >= 16) through LDS, two per pass where possible: evaluated exactly as two radix-2
+    // levels (same operations in the same order), outputs in groups of four to bound the registers
+    for (; l + 1 < levels; l += 2) {
+        const int st = 1 << l;
+        const float2 w1 = tw[l][c], w2 = tw[l + 1][c];
+        valid -= 3 * st;
+        float2 v[PER];
 #pragma unroll
-            for (int g = 0; g < PER; g += 4) {
+        for (int g = 0; g < PER; g += 4) {
 #pragma unroll
-                for (int q = g; q < g + 4; ++q) {
-                    const int j = (tid + q * 256) / CB_C;
-                    if (j < valid) {
-                        const float2 t0 = cmadd(A[j][c], w1, A[j + st][c]);
-                        const float2 t1 = cmadd(A[j + 2 * st][c], w1, A[j + 3 * st][c]);
-                        v[q] = cmadd(t0, w2, t1);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
+            for (int q = g; q < g + 4; ++q) {
                 const int j = (tid + q * 256) / CB_C;
-                if (j < valid) A[j][c] = v[q];
+                if (j < valid) {
+                    const float2 t0 = cmadd(A[j][c], w1, A[j + st][c]);
+                    const float2 t1 = cmadd(A[j + 2 * st][c], w1, A[j + 3 * st][c]);
+                    v[q] = cmadd(t0, w2, t1);
+                }
             }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = (tid + q * 256) / CB_C;
+            if (j < valid) A[j][c] = v[q];
+        }
+        __syncthreads();
     }
     for (; l < levels; ++l) {
         const int st = 1 << l;
@@ -366,7 +405,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     }
 }
 
-__global__ __launch_bounds__(256) void blockdft_gemm_tree(GemmTreeArgs a) {
+__global__ __launch_bounds__(256, 4) void blockdft_gemm_tree(GemmTreeArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FT_P_FLOATS];  // 33 KB: staging buffers, then the P tile
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
     float (*As)[FT_BM][FT_BK + 1] = reinterpret_cast<float (*)[FT_BM][FT_BK + 1]>(smem);                       // [2][128][17]
@@ -551,7 +590,7 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
     }
 }
 
-__global__ __launch_bounds__(256) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a) {
+__global__ __launch_bounds__(256, 4) void blockdft_gemm_tree_bf16x3(GemmTreeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[FB_LDS_BYTES];
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
     float* smem = reinterpret_cast<float*>(smem_raw);
