@@ -382,8 +382,7 @@ __global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames_generic(const floa
     const size_t per_wave = sizeof(float) * npad + peaks_scratch_bytes(n, a.dist);
     float* x = reinterpret_cast<float*>(pk_smem + wv * per_wave);
     unsigned char* scratch = reinterpret_cast<unsigned char*>(x + npad);
-    for (int frame = blockIdx.x * PK_WAVES + wv; frame < n_frames; frame += gridDim.x * PK_WAVES) {
-        if (redo && !redo[frame]) continue;
+    auto one = [&](int frame) {
         const float* src = db + (size_t)frame * n;
         for (int i = lane; i < n; i += 64) x[i] = src[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -391,6 +390,19 @@ __global__ __launch_bounds__(PK_WAVES * 64) void peaks_frames_generic(const floa
         peaks_wave_nk<NK>(x, scratch, (size_t)frame, a, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    };
+    if (!redo) {
+        for (int frame = blockIdx.x * PK_WAVES + wv; frame < n_frames; frame += gridDim.x * PK_WAVES) one(frame);
+        return;
+    }
+    // sweep of the (mostly clear) flags: 64 per wave and step, one ballot, then only the flagged frames
+    for (int base = (blockIdx.x * PK_WAVES + wv) * 64; base < n_frames; base += gridDim.x * PK_WAVES * 64) {
+        unsigned long long m = __ballot(base + lane < n_frames && redo[base + lane] != 0);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            one(base + b);
+        }
     }
 }
 
@@ -699,14 +711,15 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
     if (st != PVQ_OK) return st;
     uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
+    const int sweep_grid = (int)std::min<size_t>(256, (n_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES));
     const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(a.n_bins));
     if (a.n_bins <= 256) {
         hipLaunchKernelGGL(peaks_frames_lean<4>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
-        hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(std::min(grid, 512)), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
+        hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(sweep_grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
                            (int)n_frames, a, (const uint8_t*)redo);  // small grid: it only sweeps the (mostly clear) flags
     } else {
         hipLaunchKernelGGL(peaks_frames_lean<16>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
-        hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(std::min(grid, 512)), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
+        hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(sweep_grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
                            (int)n_frames, a, (const uint8_t*)redo);
     }
     return PVQ_OK;
