@@ -291,7 +291,6 @@ __device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
 // doubling tree over the [128][32 complex] P tile in LDS (rows padded to 33 so that the transposed store
 // below is bank-conflict free), then the store of the S complete frames, column-major
 constexpr int FT_LDP = CB_C + 1;                      // P tile row stride in complex elements
-constexpr int FT_P_FLOATS = FT_BM * FT_LDP * 2;       // 33 792 B
 // the tile's combine twiddles (levels x 32 columns) into LDS, issued before the K loop so the tree never waits on memory
 constexpr int FT_MAXL = 6;
 __device__ __forceinline__ void fused_stage_twiddles(float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid) {
@@ -408,27 +407,32 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     }
 }
 
-__global__ __launch_bounds__(256, 4) void blockdft_gemm_tree(GemmTreeArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[FT_P_FLOATS];  // 33 KB: staging buffers, then the P tile
+template <int BM>   // rows of hop blocks per tile; 2 * BM threads (wave tile 64 x 32)
+__global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(GemmTreeArgs a) {
+    constexpr int THREADS = 2 * BM;
+    constexpr int STAGE_FLOATS = 2 * BM * (FT_BK + 1) + 16 + 2 * FT_BK * FT_BN;
+    constexpr int P_FLOATS = BM * FT_LDP * 2;
+    __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > P_FLOATS ? STAGE_FLOATS : P_FLOATS];  // staging buffers, then the P tile
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
-    float (*As)[FT_BM][FT_BK + 1] = reinterpret_cast<float (*)[FT_BM][FT_BK + 1]>(smem);                       // [2][128][17]
-    float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * FT_BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
+    float (*As)[BM][FT_BK + 1] = reinterpret_cast<float (*)[BM][FT_BK + 1]>(smem);                          // [2][BM][17]
+    float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FusedTile T = fused_tile(a);
+    const FusedTile T = fused_tile<BM>(a);
     const BlockGroup& G = T.G;
     const int f0 = T.f0, nt = T.nt;
     if (f0 >= a.n_frames) return;
-    fused_stage_twiddles(tw_lds, T, a, tid);
+    if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
     const int wm = wave >> 1, wn = wave & 1;
     const long long s = a.base + G.s_rel;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
 
-    constexpr int A_PER = FT_BM * FT_BK / 256;          // 8
-    constexpr int A_ROWS_PER_PASS = 256 / FT_BK;        // 16
+    constexpr int A_PER = BM * FT_BK / THREADS;         // 8
+    constexpr int A_ROWS_PER_PASS = THREADS / FT_BK;    // 16 / 32
     float ra[A_PER];
     float4 rb;
     const int a_row = tid / FT_BK, a_col = tid % FT_BK;
-    const int b_row = (tid * 4) / FT_BN, b_col = (tid * 4) % FT_BN;
+    const bool stages_b = BM == 128 || tid < 256;       // the 16 x 64 E tile: 256 float4
+    const int b_row = ((tid & 255) * 4) / FT_BN, b_col = ((tid & 255) * 4) % FT_BN;
     const unsigned a_off0 = (unsigned)((s + (long long)(f0 + a_row) * a.K + a_col) * 4ll);
     const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
     const float* e_ptr = a.E + (size_t)b_row * a.ld + (size_t)nt * FT_BN + b_col;
@@ -443,12 +447,12 @@ __global__ __launch_bounds__(256, 4) void blockdft_gemm_tree(GemmTreeArgs a) {
     {                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < A_PER; ++i) ra[i] = __builtin_bit_cast(                            \
             float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
-        rb = *reinterpret_cast<const float4*>(e_ptr + (size_t)(k0) * a.ld);                                      \
+        if (stages_b) rb = *reinterpret_cast<const float4*>(e_ptr + (size_t)(k0) * a.ld);                       \
     }
 #define PVQ_FT_STORE(buf)                                                                                        \
     {                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < A_PER; ++i) As[buf][a_row + i * A_ROWS_PER_PASS][a_col] = ra[i];   \
-        *reinterpret_cast<float4*>(&Bs[buf][b_row][b_col]) = rb;                                                 \
+        if (stages_b) *reinterpret_cast<float4*>(&Bs[buf][b_row][b_col]) = rb;                                  \
     }
     const int n_iter = a.K / FT_BK;
     PVQ_FT_LOAD(0);
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256, 4) void blockdft_gemm_tree(GemmTreeArgs a) {
         smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
     }
     __syncthreads();
-    fused_tree_store(smem, tw_lds, T, a, tid);
+    fused_tree_store<BM>(smem, tw_lds, T, a, tid);
 }
 
 // Split-bf16 form of the fused kernel ("bf16x3", the default; pvq_vqt_set_gemm_precision): same tile, same
@@ -1323,7 +1327,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             static const int bm_env = getenv("PVQ_FUSED_BM") ? atoi(getenv("PVQ_FUSED_BM")) : 0;   // developer knob
             // 256-row tiles for the split-bf16 form: 257 - Nb complete frames per tile (1.08x row recomputation instead
             // of 1.2x) and the E^T planes staged once per 256 rows; measured 7 % faster than 128-row tiles
-            const int fused_bm = (use_bf && bm_env != 128) ? 256 : FT_BM;
+            const int fused_bm = bm_env != 128 ? 256 : FT_BM;
             int off = 0;
             for (int g = 0; g < t->n_groups; ++g) {
                 fa.blk_off[g] = off;
@@ -1340,8 +1344,10 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (use_bf)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<128>, dim3(off), dim3(256), 0, stream, fa);
+            else if (fused_bm == 256)
+                hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), 0, stream, fa);
             else
-                hipLaunchKernelGGL(blockdft_gemm_tree, dim3(off), dim3(256), 0, stream, fa);
+                hipLaunchKernelGGL(blockdft_gemm_tree<128>, dim3(off), dim3(256), 0, stream, fa);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
         } else {
             const int n_rows = (int)(nf + t->nb_max - 1);
