@@ -808,17 +808,59 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
     }
 }
 
-// power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins
+// power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins.  Up to 256 bins: four frames at a
+// time with their dB values in registers, so the read -> log -> reduce -> rescale chains of the frames overlap
+// (the phase is latency-bound at two waves per SIMD); more bins: one frame at a time through LDS.
 template <int MT>
 __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f0, int wave, int lane) {
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
+    // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
+    auto to_db = [&](float p) { return 3.01029995663981f * __log2f(fmaxf(p, PVQ_A_MIN)) - ref_db; };
+    if (a.n_bins <= 256) {
+        constexpr int FU = 4, NKB = 4;
+        for (int fr0 = wave; fr0 < MT * 32; fr0 += 4 * FU) {
+            float d[FU][NKB], mx[FU], mn[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                mx[u] = -3.40282347e+38f;
+                mn[u] = 3.40282347e+38f;
+#pragma unroll
+                for (int kk = 0; kk < NKB; ++kk) {
+                    const int k = lane + 64 * kk;
+                    const bool in = k < a.n_bins;
+                    d[u][kk] = to_db(in ? dbs[(fr0 + 4 * u) * a.ldb + k] : 1.0f);
+                    mx[u] = fmaxf(mx[u], in ? d[u][kk] : -3.40282347e+38f);
+                    mn[u] = fminf(mn[u], in ? d[u][kk] : 3.40282347e+38f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                mx[u] = wave_max(mx[u]);
+                mn[u] = wave_min(mn[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int fr = fr0 + 4 * u;
+                if (f0 + fr >= a.n_frames) continue;
+                const float floor_db = mx[u] - PVQ_TOP_DB;
+                const float m2 = fmaxf(mn[u], floor_db);
+                float* dst = a.out_db + (size_t)(f0 + fr) * a.n_bins;
+#pragma unroll
+                for (int kk = 0; kk < NKB; ++kk) {
+                    const int k = lane + 64 * kk;
+                    const float c = fmaxf(d[u][kk], floor_db);
+                    if (k < a.n_bins) dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
+                }
+            }
+        }
+        return;
+    }
     for (int fr = wave; fr < MT * 32; fr += 4) {
         if (f0 + fr >= a.n_frames) break;
         float* rowp = dbs + fr * a.ldb;
         float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
         for (int k = lane; k < a.n_bins; k += 64) {
-            // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
-            const float d = 3.01029995663981f * __log2f(fmaxf(rowp[k], PVQ_A_MIN)) - ref_db;
+            const float d = to_db(rowp[k]);
             rowp[k] = d;
             mx = fmaxf(mx, d);
             mn = fminf(mn, d);
