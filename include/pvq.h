@@ -139,6 +139,10 @@ typedef enum pvq_gemm_precision {
     PVQ_GEMM_BF16X3 = 1   /* split-bf16: 6 bf16 MFMAs per fp32 product block, error at fp32 rounding level */
 } pvq_gemm_precision;
 pvq_status pvq_vqt_set_gemm_precision(pvq_vqt *v, pvq_gemm_precision p);
+/* twiddle tables (FFT twiddles, real-split factors, block-DFT matrix and combine phases) rounded to IEEE half
+ * before use, accumulation in fp32: the "fp16 FFT twiddles" variant of BASELINE.json configs[3].  Off by default;
+ * switching rebuilds the device tables.  Expect ~1e-3 relative error (tests/test_configs_gpu.py reports it). */
+pvq_status pvq_vqt_set_twiddle_fp16(pvq_vqt *v, int enable);
 /* complex spectrum columns per hop block the block-DFT GEMM computes (padded), 0 before its first use */
 uint32_t pvq_vqt_blockdft_columns(const pvq_vqt *v);
 

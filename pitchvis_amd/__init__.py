@@ -347,6 +347,10 @@ class Vqt:
         """GEMM_BF16X3 (split-bf16 on the bf16 matrix cores, fp32 accumulate; default) or GEMM_F32 (fp32 MFMA)"""
         _check(self._L.pvq_vqt_set_gemm_precision(self._h, precision))
 
+    def set_twiddle_fp16(self, enable: bool) -> None:
+        """twiddle tables rounded to fp16, fp32 accumulation (BASELINE config 4's variant); rebuilds the tables"""
+        _check(self._L.pvq_vqt_set_twiddle_fp16(self._h, int(bool(enable))))
+
     def blockdft_columns(self) -> int:
         return int(self._L.pvq_vqt_blockdft_columns(self._h))
 

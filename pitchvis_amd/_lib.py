@@ -16,7 +16,7 @@ EXPORTS = [
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
-    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_blockdft_columns",
+    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
     "pvq_analysis_state_update_vqt_smoothing_duration", "pvq_analysis_state_preprocess",
     "pvq_analysis_state_bin_to_frequency", "pvq_analysis_state_n_buckets", "pvq_analysis_state_get_field",
@@ -158,6 +158,7 @@ def load():
     L.pvq_analysis_state_scene_calmness.argtypes = [vp]; L.pvq_analysis_state_scene_calmness.restype = C.c_float
     L.pvq_analysis_state_tuning_grid_inaccuracy.argtypes = [vp]; L.pvq_analysis_state_tuning_grid_inaccuracy.restype = C.c_float
     ip, bp = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.pvq_vqt_set_twiddle_fp16.argtypes = [vp, C.c_int]; L.pvq_vqt_set_twiddle_fp16.restype = C.c_int
     L.pvq_mono_agc_create.argtypes = [C.c_float, C.c_float, C.POINTER(vp)]; L.pvq_mono_agc_create.restype = C.c_int
     L.pvq_mono_agc_destroy.argtypes = [vp]
     L.pvq_mono_agc_freeze_gain.argtypes = [vp, C.c_int]

@@ -210,6 +210,11 @@ pvq_status pvq_vqt_set_algo(pvq_vqt* v, pvq_algo algo) {
 }
 pvq_algo pvq_vqt_last_algo(const pvq_vqt* v) { return v ? v->impl->last_algo() : PVQ_ALGO_AUTO; }
 
+pvq_status pvq_vqt_set_twiddle_fp16(pvq_vqt* v, int enable) {
+    if (!v) return null_handle();
+    return v->impl->set_twiddle_fp16(enable != 0);
+}
+
 uint32_t pvq_vqt_blockdft_columns(const pvq_vqt* v) { return v ? v->impl->blockdft_columns() : 0; }
 
 pvq_status pvq_vqt_set_gemm_precision(pvq_vqt* v, pvq_gemm_precision p) {

@@ -25,7 +25,10 @@ bool upload(T** dst, const std::vector<T>& src, std::string& msg) {
 }
 }  // namespace
 
-DeviceTables* build_device_tables(const HostPlan& plan, std::string& msg) {
+float round_to_half(float x) { return static_cast<float>(static_cast<_Float16>(x)); }
+
+DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::string& msg) {
+    auto q = [&](double v) { const float f = static_cast<float>(v); return twiddle_fp16 ? round_to_half(f) : f; };
     const auto& groups = plan.kernel.window_groups;
     auto* t = new DeviceTables();
     t->n_groups = static_cast<int>(groups.size());
@@ -82,7 +85,7 @@ DeviceTables* build_device_tables(const HostPlan& plan, std::string& msg) {
         d.n_cols = static_cast<int>(max_col + 1);
         for (int c = 0; c < d.n_cols; ++c) {
             const double ang = -2.0 * pi * static_cast<double>(c) / static_cast<double>(ws);
-            split_tw.push_back(make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang))));
+            split_tw.push_back(make_float2(q(std::cos(ang)), q(std::sin(ang))));
         }
         t->n_tw = std::max(t->n_tw, d.n_cplx);
         t->max_cols = std::max(t->max_cols, d.n_cols);
@@ -93,7 +96,7 @@ DeviceTables* build_device_tables(const HostPlan& plan, std::string& msg) {
     std::vector<float2> tw(static_cast<size_t>(t->n_tw));
     for (int m = 0; m < t->n_tw; ++m) {
         const double ang = -2.0 * pi * static_cast<double>(m) / static_cast<double>(t->n_tw);
-        tw[m] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        tw[m] = make_float2(q(std::cos(ang)), q(std::sin(ang)));
     }
 
     std::vector<float> lnf;

@@ -44,7 +44,11 @@ struct DeviceTables {
 };
 
 // returns nullptr and fills msg on failure ("unsupported: ..." for geometry limits)
-DeviceTables* build_device_tables(const HostPlan& plan, std::string& msg);
+// twiddle_fp16: every twiddle factor is rounded to the nearest IEEE half before use (BASELINE config 4's "fp16 FFT
+// twiddles"); the tables stay fp32 arrays and all accumulation stays fp32
+DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::string& msg);
+// value of the nearest fp16 (round to nearest even), for |x| <= 1
+float round_to_half(float x);
 void free_device_tables(DeviceTables* t);
 void free_blockdft_tables(BlockDftTables* t);
 

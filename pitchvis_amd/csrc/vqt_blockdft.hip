@@ -1144,6 +1144,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     }
     t->n_tiles = tile;
     const int ntot = tile * GM_BN;
+    auto tq = [&](double v) { const float f = (float)v; return twiddle_fp16_ ? round_to_half(f) : f; };   // config 4: fp16 twiddles
     std::vector<float> E((size_t)hop * ntot, 0.0f);
     std::vector<int> tile_group(tile);
     std::vector<float2> comb_tw((size_t)std::max(tw_off, 1), make_float2(0.0f, 0.0f));
@@ -1157,13 +1158,13 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                 // reduce the angle exactly: (c*m) mod W in integers
                 const long long prod = (c * (long long)m) % (long long)W;
                 const double ang = -2.0 * pi * (double)prod / W;
-                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci] = (float)std::cos(ang);
-                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci + 1] = (float)std::sin(ang);
+                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci] = tq(std::cos(ang));
+                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci + 1] = tq(std::sin(ang));
             }
             for (int l = 0; l < B.levels; ++l) {
                 const long long prod = (c * (1ll << l)) % (long long)B.nb;
                 const double ang = -2.0 * pi * (double)prod / (double)B.nb;
-                comb_tw[B.tw_off + l * (B.n_tiles * CB_C) + ci] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+                comb_tw[B.tw_off + l * (B.n_tiles * CB_C) + ci] = make_float2(tq(std::cos(ang)), tq(std::sin(ang)));
             }
         }
     }

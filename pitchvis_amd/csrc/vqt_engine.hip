@@ -469,9 +469,22 @@ Vqt::~Vqt() {
     }
 }
 
+pvq_status Vqt::set_twiddle_fp16(bool on) {
+    if (on == twiddle_fp16_) return PVQ_OK;
+    twiddle_fp16_ = on;
+    if (device_id_ < 0) return PVQ_OK;
+    PVQ_HIP(hipSetDevice(device_id_));
+    PVQ_HIP(hipDeviceSynchronize());
+    if (dev_) {
+        free_device_tables(dev_);   // frees the block-DFT tables too; they are rebuilt on the next batch call
+        dev_ = nullptr;
+    }
+    return upload_tables();
+}
+
 pvq_status Vqt::upload_tables() {
     std::string msg;
-    dev_ = build_device_tables(plan_, msg);
+    dev_ = build_device_tables(plan_, twiddle_fp16_, msg);
     if (!dev_) {
         set_last_error(msg);
         return msg.rfind("unsupported", 0) == 0 ? PVQ_ERR_UNSUPPORTED : PVQ_ERR_DEVICE;

@@ -64,6 +64,9 @@ class Vqt {
     void set_algo(pvq_algo a) { algo_ = a; }
     // block-DFT GEMM arithmetic: exact fp32 MFMA, or the split-bf16 (3 x bf16, fp32 accumulate) form
     void set_gemm_split_bf16(bool on) { gemm_split_bf16_ = on; }
+    // rebuilds the device tables with every twiddle factor rounded to fp16 (or back to fp32)
+    pvq_status set_twiddle_fp16(bool on);
+    bool twiddle_fp16() const { return twiddle_fp16_; }
     bool gemm_split_bf16() const { return gemm_split_bf16_; }
     uint32_t blockdft_columns() const;
     pvq_algo last_algo() const { return last_algo_; }
@@ -101,6 +104,7 @@ class Vqt {
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
     bool profiling_ = false;
+    bool twiddle_fp16_ = false;
     bool gemm_split_bf16_ = true;   // default PVQ_GEMM_BF16X3 (same parity bars as the fp32 MFMA form, ~1.3x faster)
     uint32_t last_frames_per_launch_ = 0;
     static constexpr int kMaxTimedLaunches = 512;

@@ -75,6 +75,41 @@ def test_config4_96k_stereo_hop128(name):
                       xpeak=input_peak(pcm, hop, nf, n_lead, v.window_union), sr=op.sr)
 
 
+@pytest.mark.parametrize("algo", [P.ALGO_FFT, P.ALGO_BLOCKDFT])
+def test_config4_fp16_twiddles(algo):
+    """config 4's "fp16 FFT twiddles" variant: every twiddle factor rounded to IEEE half, fp32 accumulation.  Parity is
+    relaxed and reported (expected ~1e-3 relative); switching back restores full parity."""
+    pp, op = get_geom("hires_96k_360")
+    v = P.Vqt.new(pp, 0)
+    v.set_algo(algo)
+    ov = O.OracleVqt(op)
+    hop, nf, n_lead = 128, 96, 40000
+    pcm = white_noise(n_lead + hop * nf, 0x5EED0004)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
+    fmax = np.abs(wcx).max(axis=1, keepdims=True)
+
+    def run():
+        d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
+        v.calculate_batch_db_device(d_pcm, hop, nf, d_db, n_lead=n_lead, d_out_cplx=d_cx); torch.cuda.synchronize()
+        return d_db.cpu().numpy(), d_cx.cpu().numpy().view(np.complex64)[..., 0]
+
+    db32, cx32 = run()
+    v.set_twiddle_fp16(True)
+    db16, cx16 = run()
+    v.set_twiddle_fp16(False)
+    db32b, cx32b = run()
+    e32 = (np.abs(cx32 - wcx) / fmax).max()
+    e16 = (np.abs(cx16 - wcx) / fmax).max()
+    strong = wdb > 10.0
+    print(f"fp16 twiddles ({'fft' if algo == P.ALGO_FFT else 'blockdft'}): rel err {e16:.2e} (fp32 twiddles {e32:.2e}); "
+          f"dB err on bins > 10 dB: {np.abs(db16 - wdb)[strong].max():.3f}")
+    assert e32 <= 1e-5
+    assert 1e-5 < e16 <= 5e-3                      # the quantisation is really in effect, and bounded
+    assert np.abs(db16 - wdb)[strong].max() <= 0.1
+    assert np.array_equal(cx32, cx32b) and np.array_equal(db32, db32b)
+
+
 def test_config5_polyphonic_notes():
     """config 5 with a synthetic additive piano roll (no SoundFont / MIDI assets exist here): the note
     lists of the GPU path equal the CPU oracle's, and both recover the ground truth."""
