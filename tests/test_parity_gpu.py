@@ -186,6 +186,30 @@ def test_ragged_and_edge_cases():
             assert v.last_algo() == P.ALGO_FFT or hop in (1, 256)
 
 
+@pytest.mark.parametrize("algo", [P.ALGO_BLOCKDFT, "blockdft_bf16x3"])
+def test_blockdft_tile_boundaries(algo):
+    """Frame counts around the fused tiles' edges (a 256-row tile of the 16384-sample group holds 193 complete
+    frames, a 64-frame kernel-product tile, ...), leads that are not multiples of 4 samples (dword- vs 16-byte-load
+    tiles) and a second call on the same handle: block-DFT path == FFT path == oracle."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    hop = 256
+    for nf, n_lead in ((1, 0), (2, 16129), (63, 3), (64, 40001), (65, 0), (192, 2), (193, 16128), (194, 7), (257, 33333),
+                       (450, 1)):
+        pcm = white_noise(n_lead + hop * nf, 1000 + nf)
+        _set_algo(v, algo)
+        db, cx = run_gpu(v, pcm, hop, nf, n_lead)
+        assert v.last_algo() == P.ALGO_BLOCKDFT
+        v.set_algo(P.ALGO_FFT)
+        db_f, cx_f = run_gpu(v, pcm, hop, nf, n_lead)
+        wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
+        xp = input_peak(pcm, hop, nf, n_lead, v.window_union)
+        assert_parity(db, cx, wdb, wcx, xpeak=xp, sr=op.sr)
+        fmax = np.maximum(np.abs(wcx).max(axis=1, keepdims=True), 0.01 * np.sqrt(op.sr) * xp[:, None])
+        assert (np.abs(cx - cx_f) / fmax).max() <= 1e-5
+
+
 def test_instant_api_matches_reference_semantics():
     for name in ("default_22k_588", "bench_48k_252"):
         pp, op = get_geom(name)
