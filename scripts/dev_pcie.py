@@ -1,0 +1,17 @@
+"""PCIe-inclusive rate of the host-buffer entry point (developer tool)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g; g.build()
+import pitchvis_amd as P
+pp = P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 7, 36))
+v = P.Vqt(pp, 0)
+hop, nf = 256, 65536
+pcm = ((np.random.default_rng(1).random(hop * nf, dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+for _ in range(2):
+    out = v.calculate_batch_db(pcm, hop, nf)
+t = time.perf_counter(); n = 5
+for _ in range(n):
+    out = v.calculate_batch_db(pcm, hop, nf)
+dt = (time.perf_counter() - t) / n
+print(f"host buffers (pageable numpy, 64 MiB in / 63 MiB out): {dt*1e3:.2f} ms per {nf} frames = {nf/dt/1e6:.1f} M frames/s")
