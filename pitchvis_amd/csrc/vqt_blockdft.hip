@@ -252,8 +252,8 @@ struct GemmTreeArgs {
     unsigned pcm_bytes;
     const float* E;
     int ld;                   // Ntot
-    float2* X;                // column-major: X[col * ldf + frame]
-    int ldf;
+    float2* X;                // frame-tile blocked: X[((frame / 64) * xcp + col) * 64 + frame % 64]
+    int xcp;                  // columns per frame tile (incl. the zeroed pad columns)
     int n_frames;             // frames of this launch
     int K;                    // hop
     long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
@@ -401,9 +401,9 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     const int j = tid & (BM - 1);
     const int f = t.f0 + j;
     if (j < t.S && f < a.n_frames) {
-        float2* dst = a.X + (size_t)(t.nt * CB_C) * a.ldf + f;
+        float2* dst = a.X + ((size_t)(f >> 6) * a.xcp + t.nt * CB_C) * 64 + (f & 63);
 #pragma unroll 4
-        for (int cc = tid / BM; cc < CB_C; cc += 2) dst[(size_t)cc * a.ldf] = A[j][cc];
+        for (int cc = tid / BM; cc < CB_C; cc += 2) dst[cc * 64] = A[j][cc];
     }
 }
 
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
 struct CombineArgs {
     const float* P;
     int p_rows;        // row capacity of the tile-major P
-    float2* X;         // column-major: X[col * ldf + frame]
-    int ldf;
+    float2* X;         // frame-tile blocked: X[((frame / 64) * xcp + col) * 64 + frame % 64]
+    int xcp;
     int n_frames;      // frames in this chunk
     int n_rows;        // rows of P present
     const int* tile_group;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
         const int j = tid & (CT - 1);
         const int f = f0 + j;
         if (f < a.n_frames)
-            for (int cc = tid / CT; cc < CW; cc += 256 / CT) a.X[(size_t)(col0 + cc) * a.ldf + f] = A[j][cc];
+            for (int cc = tid / CT; cc < CW; cc += 256 / CT) a.X[((size_t)(f >> 6) * a.xcp + col0 + cc) * 64 + (f & 63)] = A[j][cc];
     }
 }
 
@@ -725,8 +725,8 @@ __global__ __launch_bounds__(256) void blockdft_combine(CombineArgs a) {
 // power_to_db is applied from there.
 // ------------------------------------------------------------------------------------------------
 struct BandArgs {
-    const float* X;            // column-major complex spectrum columns, as floats
-    int ldf;                   // frames per column (allocation stride)
+    const float* X;            // complex spectrum columns, as floats: [frame / 64][column][frame % 64][re, im]
+    int xcp;                   // columns per 64-frame tile of X (incl. pad)
     int n_frames;
     int n_bins;
     int ldb;                   // LDS row stride of the dB tile
@@ -883,7 +883,8 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
     const int n = lane & 31, kx = lane >> 5;
-    const size_t col_stride = (size_t)a.ldf * 2;   // floats between consecutive X columns
+    constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
+    const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
     const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
     // MT == 2: a lane loads (Re, Im) of one of 64 frames; a half swap then leaves Re of frames 0..31 / Im of frames
     // 0..31 in the two lane halves of one register (the A operand of row tile 0) and frames 32..63 in the other.
@@ -904,8 +905,7 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
     };
     // point the operand streams at a block and put its first BD_NS - 1 stages in flight
     auto open_block = [&](const BandBlock& blk) {
-        xa = MT == 2 ? a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + lane) * 2
-                     : a.X + (size_t)blk.x0 * col_stride + (size_t)(f0 + n) * 2 + kx;
+        xa = MT == 2 ? xtile + (size_t)blk.x0 * col_stride + lane * 2 : xtile + (size_t)blk.x0 * col_stride + n * 2 + kx;
         bp = reinterpret_cast<const float2*>(a.B) + (size_t)blk.boff * 32 + lane;
 #pragma unroll
         for (int s = 0; s < BD_NS - 1; ++s) fetch(s, s * BD_KU);
@@ -980,7 +980,8 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db_bf16x3(BandArgs a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
     const int n = lane & 31, kx = lane >> 5;
-    const size_t col_stride = (size_t)a.ldf * 2;   // floats between consecutive X columns
+    constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
+    const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
     const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
     const float* xa = nullptr;
     const bf16x8* bp = nullptr;
@@ -995,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db_bf16x3(BandArgs a
             for (int q = 0; q < 4; ++q) av[s][mt][q] = *reinterpret_cast<const float2*>(xa + (size_t)(8 * g + q) * col_stride + mt * 64);
     };
     auto open_block = [&](const BandBlock& blk) {
-        xa = a.X + (size_t)(blk.x0 + 4 * kx) * col_stride + (size_t)(f0 + n) * 2;
+        xa = xtile + (size_t)(blk.x0 + 4 * kx) * col_stride + n * 2;
         bp = reinterpret_cast<const bf16x8*>(a.B3) + (size_t)blk.boff3 * 3 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < B3_NS - 1; ++s) fetch(s, s);
@@ -1300,10 +1301,10 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     const int ntot = t->n_tiles * GM_BN, xc = t->n_tiles * CB_C;
     const size_t chunk = std::min(n_frames, chunk_frames());
     const size_t rows_cap = chunk + t->nb_max - 1;
-    // X is column-major with a padded column stride (a power-of-two stride would put every column of a frame
-    // tile on the same memory channel); X_PAD_COLS zeroed columns follow the last one
-    const size_t ldf = (chunk + 63) / 64 * 64 + 64;
-    const size_t x_bytes = (size_t)(xc + X_PAD_COLS) * ldf * sizeof(float2);
+    // X is blocked by 64-frame tiles: [tile][column][64 frames], so the kernel-product workgroup of a tile streams one
+    // contiguous region (and a column step is a constant 512 bytes); X_PAD_COLS zeroed columns close every tile
+    const int xcp = xc + X_PAD_COLS;
+    const size_t x_bytes = (chunk + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
     if (t->x_cap < x_bytes) {
         if (t->d_X) PVQ_HIP(hipFree(t->d_X));
         t->d_X = nullptr; t->x_cap = 0;
@@ -1362,7 +1363,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.E = t->d_E;
             fa.ld = ntot;
             fa.X = X;
-            fa.ldf = (int)ldf;
+            fa.xcp = xcp;
             fa.n_frames = (int)nf;
             fa.K = (int)hop;
             fa.base = base;
@@ -1414,7 +1415,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             ca.P = t->d_P;
             ca.p_rows = (int)rows_cap;
             ca.X = X;
-            ca.ldf = (int)ldf;
+            ca.xcp = xcp;
             ca.n_frames = (int)nf;
             ca.n_rows = n_rows;
             ca.tile_group = t->d_tile_group;
@@ -1431,7 +1432,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         }
         BandArgs da;
         da.X = reinterpret_cast<const float*>(X);
-        da.ldf = (int)ldf;
+        da.xcp = xcp;
         da.n_frames = (int)nf;
         da.n_bins = nb;
         da.ldb = t->n_bins_pad + 4;   // 4 rows apart (the two lane halves of a C tile) land 16 banks apart
