@@ -381,13 +381,20 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         // pL / pR: a sample higher than the peak has been met on that side (later samples no longer count)
         bool pL = false, pR = false;
         float mL = INF, mR = INF;
+        // in blocks of four steps; the walk stops once every lane of the pass has both sides settled (a higher
+        // sample met, or the prominence already reached — the minimum only falls, so that verdict is final)
 #pragma unroll
-        for (int s = 1; s <= PK_PAD; ++s) {
-            const float vl = x[i - s], vr = x[i + s];
-            pL |= vl > xv;
-            pR |= vr > xv;
-            mL = fminf(mL, pL ? INF : vl);
-            mR = fminf(mR, pR ? INF : vr);
+        for (int s0 = 1; s0 <= PK_PAD; s0 += 4) {
+#pragma unroll
+            for (int s = s0; s < s0 + 4; ++s) {
+                const float vl = x[i - s], vr = x[i + s];
+                pL |= vl > xv;
+                pR |= vr > xv;
+                mL = fminf(mL, pL ? INF : vl);
+                mR = fminf(mR, pR ? INF : vr);
+            }
+            const bool open = have && (!(pL || (xv - mL >= P)) || !(pR || (xv - mR >= P)));
+            if (!__ballot(open)) break;
         }
         const bool noP = !(P > 0.0f);
         const bool okL = noP || (xv - mL >= P), okR = noP || (xv - mR >= P);
