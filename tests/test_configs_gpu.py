@@ -142,3 +142,31 @@ def test_config5_polyphonic_notes():
           f"frames whose GPU note list differs from the oracle's: {mismatched}/{nf}")
     assert mismatched <= nf // 50          # only threshold-straddling peaks (size within tolerance of 12 dB) may differ
     assert recall >= 0.9 and spectral_precision >= 0.9
+
+
+def test_two_handles_two_streams():
+    """Handles are independent (one per thread / stream): two of them driven on two non-default streams,
+    interleaved, give the same bits as each alone."""
+    pp, _ = get_geom("bench_48k_252")
+    va, vb = P.Vqt.new(pp, 0), P.Vqt.new(pp, 0)
+    hop, nf = 256, 1500
+    pa = torch.from_numpy(white_noise(hop * nf, 71)).cuda()
+    pb = torch.from_numpy(white_noise(hop * nf, 72)).cuda()
+    words = (va.n_bins + 31) // 32
+
+    def bufs():
+        return (torch.empty((nf, va.n_bins), device="cuda"), torch.zeros((nf, words), dtype=torch.int32, device="cuda"),
+                torch.zeros(nf, dtype=torch.int32, device="cuda"))
+
+    ra, rb = bufs(), bufs()
+    va.vqt_analyze_batch_device(pa, hop, nf, *ra)
+    vb.vqt_analyze_batch_device(pb, hop, nf, *rb)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    qa, qb = bufs(), bufs()
+    for _ in range(3):
+        va.vqt_analyze_batch_device(pa, hop, nf, *qa, stream=sa)
+        vb.vqt_analyze_batch_device(pb, hop, nf, *qb, stream=sb)
+    torch.cuda.synchronize()
+    for x, y in zip(ra + rb, qa + qb):
+        assert torch.equal(x, y)
