@@ -300,6 +300,12 @@ void pvq_calculate_color(uint16_t buckets_per_octave, float bucket, const float 
 size_t pvq_led_frame(uint32_t n_buckets, uint16_t buckets_per_octave, const float *center, const float *size,
                      uint32_t n_peaks, const float *colors, float gray_level, float easing_pow, uint8_t *out);
 
+/* Page-locked host memory for the host-buffer entry points (pvq_vqt_calculate_batch_db, pvq_analyze_batch,
+ * pvq_train_frames_db): with pageable buffers those calls are bound by staged PCIe copies (~16 GB/s); buffers from
+ * here are DMA-able directly.  NULL on failure (pvq_last_error). */
+void *pvq_host_alloc(size_t bytes);
+void pvq_host_free(void *p);
+
 /* timing hook for bench.py: elapsed GPU milliseconds of the dominant kernel launches of the
  * last batch call, measured with HIP events on the stream the kernels were launched on.
  * Enable with pvq_vqt_set_profiling(v, 1) (resets the statistics); reading synchronises. */

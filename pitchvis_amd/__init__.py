@@ -480,4 +480,4 @@ class AnalysisState:
     def smoothed_tuning_grid_inaccuracy(self) -> float:
         return float(self._L.pvq_analysis_state_tuning_grid_inaccuracy(self._h))
 
-from .consumers import MonoAgc, Stream, calculate_color, led_frame, train_chunk_samples, train_dataset, write_npy  # noqa: E402,F401
+from .consumers import MonoAgc, PinnedArray, Stream, calculate_color, led_frame, train_chunk_samples, train_dataset, write_npy  # noqa: E402,F401

@@ -26,7 +26,7 @@ EXPORTS = [
     "pvq_mono_agc_gain", "pvq_mono_agc_process", "pvq_train_chunk_samples", "pvq_train_condition_stream",
     "pvq_train_frames_db", "pvq_train_rows", "pvq_npy_write_f32", "pvq_stream_create", "pvq_stream_destroy",
     "pvq_stream_push", "pvq_stream_gain", "pvq_stream_chunk_size_ms", "pvq_stream_frame_db", "pvq_stream_read",
-    "pvq_calculate_color", "pvq_led_frame",
+    "pvq_calculate_color", "pvq_led_frame", "pvq_host_alloc", "pvq_host_free",
 ]
 
 PVQ_OK = 0
@@ -181,5 +181,7 @@ def load():
     L.pvq_calculate_color.argtypes = [C.c_uint16, C.c_float, fp, C.c_float, C.c_float, fp]
     L.pvq_led_frame.argtypes = [C.c_uint32, C.c_uint16, fp, fp, C.c_uint32, fp, C.c_float, C.c_float, bp]
     L.pvq_led_frame.restype = C.c_size_t
+    L.pvq_host_alloc.argtypes = [C.c_size_t]; L.pvq_host_alloc.restype = C.c_void_p
+    L.pvq_host_free.argtypes = [C.c_void_p]
     _lib = L
     return L

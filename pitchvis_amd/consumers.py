@@ -152,6 +152,26 @@ class Stream:
         return out
 
 
+class PinnedArray:
+    """float32 NumPy view of page-locked host memory (pvq_host_alloc): hand `.array` to the host-buffer entry points"""
+
+    def __init__(self, shape):
+        self._L = _lib.load()
+        n = int(np.prod(shape))
+        self._p = self._L.pvq_host_alloc(4 * max(n, 1))
+        if not self._p:
+            raise MemoryError((self._L.pvq_last_error() or b"").decode())
+        buf = (C.c_float * max(n, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=np.float32, count=n).reshape(shape)
+
+    def __del__(self):
+        p = getattr(self, "_p", None)
+        if p:
+            self.array = None
+            self._L.pvq_host_free(p)
+            self._p = None
+
+
 # pitchvis_colors/src/lib.rs:19-36
 COLORS = np.array([
     [0.85, 0.36, 0.36], [0.01, 0.52, 0.71], [0.97, 0.76, 0.05], [0.45, 0.34, 0.63], [0.47, 0.77, 0.22], [0.78, 0.32, 0.52],

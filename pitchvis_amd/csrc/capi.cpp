@@ -541,6 +541,19 @@ pvq_status pvq_stream_read(pvq_stream* s, float* out, size_t n_last) {
     return PVQ_OK;
 }
 
+void* pvq_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        pvq::set_last_error(std::string("hipHostMalloc failed: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+void pvq_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 void pvq_calculate_color(uint16_t buckets_per_octave, float bucket, const float* colors, float gray_level, float easing_pow,
                          float out_rgb[3]) {
     pvq::calculate_color(buckets_per_octave, bucket, reinterpret_cast<const float(*)[3]>(colors), gray_level, easing_pow, out_rgb);

@@ -123,3 +123,17 @@ def test_stream_ring_and_frames():
         s.push(np.zeros(bufsize + 1, np.float32))
     with pytest.raises(P.PvqError):
         P.Stream(v, 1000)
+
+
+def test_pinned_host_buffers():
+    """pvq_host_alloc: page-locked buffers for the host-buffer entry points give the same bits as pageable ones"""
+    pp, _ = _train_params()
+    v = P.Vqt.new(pp, 0)
+    hop, nf = 256, 300
+    pcm = (np.random.default_rng(3).standard_normal(hop * nf) * 0.1).astype(np.float32)
+    want = v.calculate_batch_db(pcm, hop, nf)
+    pin = P.PinnedArray((hop * nf,))
+    pin.array[:] = pcm
+    got = v.calculate_batch_db(pin.array, hop, nf)
+    assert np.array_equal(got, want)
+    del pin
