@@ -463,6 +463,9 @@ Vqt::~Vqt() {
         if (ws_out_) (void)hipFree(ws_out_);
         if (ws_misc_) (void)hipFree(ws_misc_);
         if (ws_flags_) (void)hipFree(ws_flags_);
+        if (host_streams_ready_)
+            for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(host_streams_[i]);
+        for (hipEvent_t e : host_events_) (void)hipEventDestroy(e);
         for (int s = 0; s < N_SLOTS; ++s)
             for (int k = 0; k < 2; ++k)
                 for (hipEvent_t e : ev_[s][k]) (void)hipEventDestroy(e);
@@ -691,11 +694,49 @@ pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, 
     if (st != PVQ_OK) return st;
     st = ensure_workspace(&ws_out_, &ws_out_cap_, n_frames * n_bins() * sizeof(float));
     if (st != PVQ_OK) return st;
-    PVQ_HIP(hipMemcpy(ws_pcm_, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice));
-    st = calculate_batch_db_device(static_cast<const float*>(ws_pcm_), n_lead, hop, n_frames,
-                                   static_cast<float*>(ws_out_), nullptr, nullptr);
-    if (st != PVQ_OK) return st;
-    PVQ_HIP(hipMemcpy(out_db, ws_out_, n_frames * n_bins() * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t nb = n_bins();
+    constexpr size_t PART = 16384;   // frames per pipeline part
+    if (n_frames < 2 * PART) {
+        PVQ_HIP(hipMemcpy(ws_pcm_, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice));
+        st = calculate_batch_db_device(static_cast<const float*>(ws_pcm_), n_lead, hop, n_frames,
+                                       static_cast<float*>(ws_out_), nullptr, nullptr);
+        if (st != PVQ_OK) return st;
+        PVQ_HIP(hipMemcpy(out_db, ws_out_, n_frames * nb * sizeof(float), hipMemcpyDeviceToHost));
+        return PVQ_OK;
+    }
+    // Large batches: upload, transform and download in parts on three streams, so that with page-locked host buffers
+    // (pvq_host_alloc) the two PCIe directions and the kernels overlap.  Part p's frames see the parts before it as
+    // history (n_lead grows), so the results are those of one call.  Pageable buffers make the copies synchronous:
+    // same results, no overlap.
+    if (!host_streams_ready_) {
+        for (int i = 0; i < 3; ++i) PVQ_HIP(hipStreamCreateWithFlags(&host_streams_[i], hipStreamNonBlocking));
+        host_streams_ready_ = true;
+    }
+    hipStream_t s_in = host_streams_[0], s_run = host_streams_[1], s_out = host_streams_[2];
+    const size_t n_parts = (n_frames + PART - 1) / PART;
+    while (host_events_.size() < 2 * n_parts) {
+        hipEvent_t e;
+        PVQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        host_events_.push_back(e);
+    }
+    float* d_pcm = static_cast<float*>(ws_pcm_);
+    float* d_out = static_cast<float*>(ws_out_);
+    size_t sample_done = 0;
+    for (size_t p = 0; p < n_parts; ++p) {
+        const size_t fbeg = p * PART, nf = std::min(PART, n_frames - fbeg);
+        const size_t sample_end = n_lead + (fbeg + nf) * hop;
+        PVQ_HIP(hipMemcpyAsync(d_pcm + sample_done, pcm + sample_done, (sample_end - sample_done) * sizeof(float), hipMemcpyHostToDevice, s_in));
+        sample_done = sample_end;
+        PVQ_HIP(hipEventRecord(host_events_[2 * p], s_in));
+        PVQ_HIP(hipStreamWaitEvent(s_run, host_events_[2 * p], 0));
+        st = calculate_batch_db_device(d_pcm, n_lead + fbeg * hop, hop, nf, d_out + fbeg * nb, nullptr, s_run);
+        if (st != PVQ_OK) return st;
+        PVQ_HIP(hipEventRecord(host_events_[2 * p + 1], s_run));
+        PVQ_HIP(hipStreamWaitEvent(s_out, host_events_[2 * p + 1], 0));
+        PVQ_HIP(hipMemcpyAsync(out_db + fbeg * nb, d_out + fbeg * nb, nf * nb * sizeof(float), hipMemcpyDeviceToHost, s_out));
+    }
+    PVQ_HIP(hipStreamSynchronize(s_out));
+    PVQ_HIP(hipStreamSynchronize(s_run));
     return PVQ_OK;
 }
 

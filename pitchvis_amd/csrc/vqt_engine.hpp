@@ -104,6 +104,10 @@ class Vqt {
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
     bool profiling_ = false;
+    // host-buffer batches: upload / run / download streams and their events
+    bool host_streams_ready_ = false;
+    hipStream_t host_streams_[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> host_events_;
     bool twiddle_fp16_ = false;
     bool gemm_split_bf16_ = true;   // default PVQ_GEMM_BF16X3 (same parity bars as the fp32 MFMA form, ~1.3x faster)
     uint32_t last_frames_per_launch_ = 0;

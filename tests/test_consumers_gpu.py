@@ -137,3 +137,15 @@ def test_pinned_host_buffers():
     got = v.calculate_batch_db(pin.array, hop, nf)
     assert np.array_equal(got, want)
     del pin
+    # a batch large enough for the three-stream upload / run / download pipeline: same bits as the device entry point
+    import torch
+    nf = 40000
+    pcm = (np.random.default_rng(4).standard_normal(1000 + hop * nf) * 0.1).astype(np.float32)
+    d_db = torch.empty((nf, v.n_bins), device="cuda")
+    v.calculate_batch_db_device(torch.from_numpy(pcm).cuda(), hop, nf, d_db, n_lead=1000)
+    torch.cuda.synchronize()
+    want = d_db.cpu().numpy()
+    assert np.array_equal(v.calculate_batch_db(pcm, hop, nf, n_lead=1000), want)
+    pin = P.PinnedArray((pcm.size,))
+    pin.array[:] = pcm
+    assert np.array_equal(v.calculate_batch_db(pin.array, hop, nf, n_lead=1000), want)
