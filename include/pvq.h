@@ -132,8 +132,9 @@ pvq_status pvq_vqt_set_algo(pvq_vqt *v, pvq_algo algo);
 /* which algorithm the last batch call actually used */
 pvq_algo pvq_vqt_last_algo(const pvq_vqt *v);
 
-/* arithmetic of the block-DFT GEMM (default PVQ_GEMM_BF16X3).  Both accumulate in fp32 and meet the same
- * parity bars; PVQ_GEMM_BF16X3 writes each fp32 operand as three bf16 terms and uses the bf16 matrix cores. */
+/* arithmetic of the block-DFT GEMM and kernel product (default PVQ_GEMM_F32).  Both accumulate in fp32 and meet the
+ * same parity bars; PVQ_GEMM_BF16X3 writes each fp32 operand exactly as three bf16 terms and uses the bf16 matrix
+ * cores (six exact partial products per fp32 product, dropped terms < 2^-24): ~10 % faster end to end. */
 typedef enum pvq_gemm_precision {
     PVQ_GEMM_F32 = 0,     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
     PVQ_GEMM_BF16X3 = 1   /* split-bf16: 6 bf16 MFMAs per fp32 product block, error at fp32 rounding level */

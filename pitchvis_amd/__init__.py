@@ -344,7 +344,8 @@ class Vqt:
         _check(self._L.pvq_vqt_set_algo(self._h, algo))
 
     def set_gemm_precision(self, precision: int) -> None:
-        """GEMM_BF16X3 (split-bf16 on the bf16 matrix cores, fp32 accumulate; default) or GEMM_F32 (fp32 MFMA)"""
+        """GEMM_F32 (fp32 MFMA, default) or GEMM_BF16X3 (fp32 operands split exactly into three bf16 terms on the bf16
+        matrix cores, fp32 accumulate: same parity bars, ~10 % faster end to end)"""
         _check(self._L.pvq_vqt_set_gemm_precision(self._h, precision))
 
     def set_twiddle_fp16(self, enable: bool) -> None:

@@ -109,7 +109,7 @@ class Vqt {
     hipStream_t host_streams_[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> host_events_;
     bool twiddle_fp16_ = false;
-    bool gemm_split_bf16_ = true;   // default PVQ_GEMM_BF16X3 (same parity bars as the fp32 MFMA form, ~1.3x faster)
+    bool gemm_split_bf16_ = false;  // default PVQ_GEMM_F32; PVQ_GEMM_BF16X3 meets the same parity bars and is ~10 % faster end to end
     uint32_t last_frames_per_launch_ = 0;
     static constexpr int kMaxTimedLaunches = 512;
     std::vector<hipEvent_t> ev_[N_SLOTS][2];  // event pool, grown on demand
