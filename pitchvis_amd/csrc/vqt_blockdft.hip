@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "device_tables.hpp"
 #include "peaks_device.hpp"
@@ -808,7 +809,7 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
     }
 }
 
-// power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins.  Up to 256 bins: four frames at a
+// power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins.  Up to 512 bins: four (two) frames at a
 // time with their dB values in registers, so the read -> log -> reduce -> rescale chains of the frames overlap
 // (the phase is latency-bound at two waves per SIMD); more bins: one frame at a time through LDS.
 template <int MT>
@@ -816,8 +817,8 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
     auto to_db = [&](float p) { return 3.01029995663981f * __log2f(fmaxf(p, PVQ_A_MIN)) - ref_db; };
-    if (a.n_bins <= 256) {
-        constexpr int FU = 4, NKB = 4;
+    auto in_registers = [&](auto fu_c, auto nkb_c) {
+        constexpr int FU = decltype(fu_c)::value, NKB = decltype(nkb_c)::value;
         for (int fr0 = wave; fr0 < MT * 32; fr0 += 4 * FU) {
             float d[FU][NKB], mx[FU], mn[FU];
 #pragma unroll
@@ -853,6 +854,13 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
                 }
             }
         }
+    };
+    if (a.n_bins <= 256) {
+        in_registers(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+        return;
+    }
+    if (a.n_bins <= 512) {
+        in_registers(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
         return;
     }
     for (int fr = wave; fr < MT * 32; fr += 4) {

@@ -753,13 +753,17 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     const int npad = (a.n_bins + 63) / 64 * 64;
     const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
     const size_t lds_gen = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
-    if (a.dist > 1) {
+    // bins per lane: 4 (<= 256 bins), 8 (<= 512) or 16 (<= 1024)
+    auto launch_generic = [&](int g, const uint8_t* flags) {
         if (a.n_bins <= 256)
-            hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a,
-                               (const uint8_t*)nullptr);
+            hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
+        else if (a.n_bins <= 512)
+            hipLaunchKernelGGL(peaks_frames_generic<8>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
         else
-            hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a,
-                               (const uint8_t*)nullptr);
+            hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
+    };
+    if (a.dist > 1) {
+        launch_generic(grid, nullptr);
         return PVQ_OK;
     }
     pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
@@ -767,15 +771,13 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
     const int sweep_grid = (int)std::min<size_t>(256, (n_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES));
     const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(a.n_bins));
-    if (a.n_bins <= 256) {
+    if (a.n_bins <= 256)
         hipLaunchKernelGGL(peaks_frames_lean<4>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
-        hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(sweep_grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
-                           (int)n_frames, a, (const uint8_t*)redo);  // small grid: it only sweeps the (mostly clear) flags
-    } else {
+    else if (a.n_bins <= 512)
+        hipLaunchKernelGGL(peaks_frames_lean<8>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+    else
         hipLaunchKernelGGL(peaks_frames_lean<16>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
-        hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(sweep_grid), dim3(PK_WAVES * 64), lds_gen, stream, d_db,
-                           (int)n_frames, a, (const uint8_t*)redo);
-    }
+    launch_generic(sweep_grid, redo);   // small grid: it only sweeps the (mostly clear) flags
     return PVQ_OK;
 }
 
