@@ -198,6 +198,67 @@ __device__ inline void pk_distance_filter(const float* x, int n, const uint8_t* 
     }
 }
 
+// The same greedy distance suppression as pk_distance_filter, evaluated by the whole wave.  Sequentially, candidates
+// are visited from the highest to the lowest (ties: the later position first) and a visited candidate that is still
+// kept removes every other candidate closer than `dist`.  Equivalently, a candidate is kept iff no higher-priority
+// candidate within `dist` is kept: decided in rounds — a candidate whose higher-priority neighbours are all decided
+// becomes kept (none of them kept) or removed (one of them kept).  Each round settles at least the highest
+// undecided candidate of every neighbourhood; a noisy frame needs a handful of rounds.
+// keep[i]: 0 = no candidate / removed, 1 = kept, 2 = undecided (on return only 0 / 1).
+template <int NK>
+__device__ __forceinline__ void pk_distance_wave(const float* x, int n, const uint8_t* cand, float min_height, int dist, uint8_t* keep,
+                                                 int lane) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i = (k << 6) + lane;
+        if (i < n) keep[i] = (cand[i] && x[i] >= min_height) ? 2 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int round = 0; round < n; ++round) {   // terminates long before: every round decides at least one candidate
+        uint8_t nxt[NK];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = (k << 6) + lane;
+            nxt[k] = 0;
+            if (i < n) {
+                nxt[k] = keep[i];
+                if (nxt[k] == 2) {
+                    const float h = x[i];
+                    bool blocked = false, killed = false;
+                    for (int d = 1; d < dist; ++d) {
+#pragma unroll
+                        for (int sgn = -1; sgn <= 1; sgn += 2) {
+                            const int j = i + sgn * d;
+                            if (j < 0 || j >= n) continue;
+                            const uint8_t sj = keep[j];
+                            if (sj == 0) continue;
+                            const float hj = x[j];
+                            const bool higher = hj > h || (hj == h && j > i);
+                            if (!higher) continue;
+                            if (sj == 1) killed = true;
+                            else blocked = true;
+                        }
+                    }
+                    nxt[k] = killed ? 0 : (blocked ? 2 : 1);
+                    any |= nxt[k] == 2;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // every lane has read the old states
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = (k << 6) + lane;
+            if (i < n) keep[i] = nxt[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!__ballot(any)) break;
+    }
+}
+
 // x: the frame's dB values in LDS (n_bins <= 64*NK floats, already visible to the whole wave);
 // scratch: peaks_scratch_bytes() bytes of LDS private to this wave.  Called by all 64 lanes.
 template <int NK>
@@ -210,8 +271,6 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);  // compacted peak bins, ascending
     uint8_t* keep0 = scratch + 2 * npad;
     uint8_t* keep1 = keep0 + npad;
-    uint16_t* list = reinterpret_cast<uint16_t*>(keep1 + npad);
-    uint16_t* order = list + npad;
 
     // frame minimum: a peak of height h can only reach prominence P if fl(h - min) >= P, which
     // rejects the many low local maxima of a noisy frame without walking at all
@@ -235,12 +294,8 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.dist > 1) {
-        if (lane == 0) {
-            pk_distance_filter(x, n, cand, a.bass_min_height, a.dist, keep0, list, order);
-            pk_distance_filter(x, n, cand, a.peak_min_height, a.dist, keep1, list, order);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        pk_distance_wave<NK>(x, n, cand, a.bass_min_height, a.dist, keep0, lane);
+        pk_distance_wave<NK>(x, n, cand, a.peak_min_height, a.dist, keep1, lane);
     }
     float v[NK];
 #pragma unroll
@@ -320,12 +375,12 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
 constexpr int PK_PAD = 16;
 
 // LDS scratch of the lean routine besides the frame: candidate list (u16), peak list (u16), peak flags (u8)
-__host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins) {
+__host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return 3 * n;
+    return 3 * n + (dist > 1 ? 3 * n /*local maxima, kept at the bass / general height*/ : 0);
 }
 
-template <int NK>
+template <int NK, bool DISTANCE>   // DISTANCE: min_distance > 1 (84 bins per octave)
 __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
                                                 int lane) {
     const int n = a.n_bins;
@@ -335,6 +390,9 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
     uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);   // peaks, ascending
     uint8_t* flag = scratch + 2 * npad;                              // flag[bin] = 1 for a peak
+    uint8_t* lmax = scratch + 3 * npad;                              // dist > 1 only: strict local maxima,
+    uint8_t* keep0 = lmax + npad;                                    //   survivors of the distance rule at the bass height,
+    uint8_t* keep1 = keep0 + npad;                                   //   and at the general height
     float v[NK];
     float fmin_ = INF;
     bool plateau = false;
@@ -346,8 +404,13 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         // a rise followed by an equal sample may start a plateau peak: leave those frames to the generic code
         plateau |= (i >= 1 && i < n - 1) && (x[i - 1] < v[k]) && (x[i + 1] == v[k]);
         if (i < npad) flag[i] = 0;
+        if (DISTANCE && i < npad) lmax[i] = (i >= 1 && i < n - 1 && x[i - 1] < v[k] && x[i + 1] < v[k]) ? 1 : 0;
     }
     if (__ballot(plateau)) return false;
+    if (DISTANCE) {   // find_peaks' distance rule runs before its prominence test, once per height threshold
+        pk_distance_wave<NK>(x, n, lmax, a.bass_min_height, a.dist, keep0, lane);
+        pk_distance_wave<NK>(x, n, lmax, a.peak_min_height, a.dist, keep1, lane);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
 
@@ -362,8 +425,9 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
         const float H = bass ? a.bass_min_height : a.peak_min_height;
         const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
-        const bool pre = (i >= a.min_bin) && (i < n) && (x[i - 1] < xv) && (x[i + 1] < xv) && (xv >= H) &&
-                         (!(P > 0.0f) || (xv - fmin_ >= P));
+        bool pre = (i >= a.min_bin) && (i < n) && (x[i - 1] < xv) && (x[i + 1] < xv) && (xv >= H) &&
+                   (!(P > 0.0f) || (xv - fmin_ >= P));
+        if (DISTANCE && pre) pre = (bass ? keep0[i] : keep1[i]) != 0;
         const unsigned long long bm = __ballot(pre);
         if (pre) clist[n_cand + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)i;
         n_cand += __popcll(bm);

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "device_tables.hpp"
 #include "peaks_device.hpp"
@@ -346,14 +347,14 @@ constexpr int PK_WAVES = 4;
 
 // Common case (min_distance <= 1 and no plateau peak in the frame): the lean routine.  A frame it
 // cannot take is flagged for peaks_frames_generic, which is launched right behind it.
-template <int NK>
-__global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
+template <int NK, bool DISTANCE>
+__global__ __launch_bounds__(PK_WAVES * 64, NK <= 8 ? 8 : 4) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
                                                                        uint8_t* __restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
-    const size_t per_wave = sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(n);
+    const size_t per_wave = sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(n, a.dist);
     float* xs = reinterpret_cast<float*>(pk_smem + wv * per_wave);
     float* x = xs + PK_PAD;  // x[-PK_PAD..-1] and x[n..npad+PK_PAD-1] hold +INF sentinels
     unsigned char* scratch = reinterpret_cast<unsigned char*>(xs + npad + 2 * PK_PAD);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, 8) void peaks_frames_lean(const floa
         for (int i = lane; i < n; i += 64) x[i] = src[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool done = peaks_wave_lean<NK>(x, scratch, (size_t)frame, a, lane);
+        const bool done = peaks_wave_lean<NK, DISTANCE>(x, scratch, (size_t)frame, a, lane);
         if (lane == 0) redo[frame] = done ? 0 : 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -762,21 +763,26 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
         else
             hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
     };
-    if (a.dist > 1) {
-        launch_generic(grid, nullptr);
-        return PVQ_OK;
-    }
     pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
     if (st != PVQ_OK) return st;
     uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
     const int sweep_grid = (int)std::min<size_t>(256, (n_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES));
-    const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(a.n_bins));
-    if (a.n_bins <= 256)
-        hipLaunchKernelGGL(peaks_frames_lean<4>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
-    else if (a.n_bins <= 512)
-        hipLaunchKernelGGL(peaks_frames_lean<8>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
-    else
-        hipLaunchKernelGGL(peaks_frames_lean<16>, dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+    const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(a.n_bins, a.dist));
+    auto launch_lean = [&](auto nk_c, auto dist_c) {
+        constexpr int NK = decltype(nk_c)::value;
+        constexpr bool D = decltype(dist_c)::value;
+        hipLaunchKernelGGL((peaks_frames_lean<NK, D>), dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+    };
+    using std::integral_constant;
+    if (a.dist > 1) {
+        if (a.n_bins <= 256) launch_lean(integral_constant<int, 4>{}, std::true_type{});
+        else if (a.n_bins <= 512) launch_lean(integral_constant<int, 8>{}, std::true_type{});
+        else launch_lean(integral_constant<int, 16>{}, std::true_type{});
+    } else {
+        if (a.n_bins <= 256) launch_lean(integral_constant<int, 4>{}, std::false_type{});
+        else if (a.n_bins <= 512) launch_lean(integral_constant<int, 8>{}, std::false_type{});
+        else launch_lean(integral_constant<int, 16>{}, std::false_type{});
+    }
     launch_generic(sweep_grid, redo);   // small grid: it only sweeps the (mostly clear) flags
     return PVQ_OK;
 }
