@@ -38,7 +38,7 @@ namespace pvq {
     } while (0)
 
 constexpr int GM_BN = 64;   // granularity of the column tiling: 64 floats = 32 complex spectrum columns
-constexpr int CB_T = 64;    // frames per combine workgroup
+constexpr int CB_T = 128;    // frames per combine workgroup
 constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
 static size_t chunk_frames() {  // frames per sub-batch: P and X of one chunk should stay in the Infinity Cache
