@@ -205,57 +205,50 @@ __device__ inline void pk_distance_filter(const float* x, int n, const uint8_t* 
 // becomes kept (none of them kept) or removed (one of them kept).  Each round settles at least the highest
 // undecided candidate of every neighbourhood; a noisy frame needs a handful of rounds.
 // keep[i]: 0 = no candidate / removed, 1 = kept, 2 = undecided (on return only 0 / 1).
-template <int NK>
+// tmp: npad bytes of scratch (the states ping-pong between keep and tmp, a round reads one and writes the other)
 __device__ __forceinline__ void pk_distance_wave(const float* x, int n, const uint8_t* cand, float min_height, int dist, uint8_t* keep,
-                                                 int lane) {
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int i = (k << 6) + lane;
-        if (i < n) keep[i] = (cand[i] && x[i] >= min_height) ? 2 : 0;
-    }
+                                                 uint8_t* tmp, int lane) {
+    for (int i = lane; i < n; i += 64) keep[i] = (cand[i] && x[i] >= min_height) ? 2 : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    uint8_t* cur = keep;
+    uint8_t* nxt = tmp;
     for (int round = 0; round < n; ++round) {   // terminates long before: every round decides at least one candidate
-        uint8_t nxt[NK];
         bool any = false;
+        for (int i = lane; i < n; i += 64) {
+            uint8_t st = cur[i];
+            if (st == 2) {
+                const float h = x[i];
+                bool blocked = false, killed = false;
+                for (int d = 1; d < dist; ++d) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int i = (k << 6) + lane;
-            nxt[k] = 0;
-            if (i < n) {
-                nxt[k] = keep[i];
-                if (nxt[k] == 2) {
-                    const float h = x[i];
-                    bool blocked = false, killed = false;
-                    for (int d = 1; d < dist; ++d) {
-#pragma unroll
-                        for (int sgn = -1; sgn <= 1; sgn += 2) {
-                            const int j = i + sgn * d;
-                            if (j < 0 || j >= n) continue;
-                            const uint8_t sj = keep[j];
-                            if (sj == 0) continue;
-                            const float hj = x[j];
-                            const bool higher = hj > h || (hj == h && j > i);
-                            if (!higher) continue;
-                            if (sj == 1) killed = true;
-                            else blocked = true;
-                        }
+                    for (int sgn = -1; sgn <= 1; sgn += 2) {
+                        const int j = i + sgn * d;
+                        if (j < 0 || j >= n) continue;
+                        const uint8_t sj = cur[j];
+                        if (sj == 0) continue;
+                        const float hj = x[j];
+                        if (!(hj > h || (hj == h && j > i))) continue;   // lower priority: cannot remove this one
+                        if (sj == 1) killed = true;
+                        else blocked = true;
                     }
-                    nxt[k] = killed ? 0 : (blocked ? 2 : 1);
-                    any |= nxt[k] == 2;
                 }
+                st = killed ? 0 : (blocked ? 2 : 1);
+                any |= st == 2;
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // every lane has read the old states
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int i = (k << 6) + lane;
-            if (i < n) keep[i] = nxt[k];
+            nxt[i] = st;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        uint8_t* t = cur;
+        cur = nxt;
+        nxt = t;
         if (!__ballot(any)) break;
+    }
+    if (cur != keep) {
+        for (int i = lane; i < n; i += 64) keep[i] = cur[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -294,8 +287,9 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.dist > 1) {
-        pk_distance_wave<NK>(x, n, cand, a.bass_min_height, a.dist, keep0, lane);
-        pk_distance_wave<NK>(x, n, cand, a.peak_min_height, a.dist, keep1, lane);
+        uint8_t* tmp = keep1 + npad;   // the area the serial filter used for its sort lists
+        pk_distance_wave(x, n, cand, a.bass_min_height, a.dist, keep0, tmp, lane);
+        pk_distance_wave(x, n, cand, a.peak_min_height, a.dist, keep1, tmp, lane);
     }
     float v[NK];
 #pragma unroll
@@ -408,8 +402,9 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     }
     if (__ballot(plateau)) return false;
     if (DISTANCE) {   // find_peaks' distance rule runs before its prominence test, once per height threshold
-        pk_distance_wave<NK>(x, n, lmax, a.bass_min_height, a.dist, keep0, lane);
-        pk_distance_wave<NK>(x, n, lmax, a.peak_min_height, a.dist, keep1, lane);
+        pk_distance_wave(x, n, lmax, a.bass_min_height, a.dist, keep0, flag, lane);
+        pk_distance_wave(x, n, lmax, a.peak_min_height, a.dist, keep1, flag, lane);
+        for (int i = lane; i < npad; i += 64) flag[i] = 0;   // it served as the ping-pong buffer
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));

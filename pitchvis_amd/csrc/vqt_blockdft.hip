@@ -81,6 +81,7 @@ struct BlockDftTables {
     std::vector<BlockGroup> groups;
     std::vector<float> h_E;        // host copy of E
     float* d_E = nullptr;          // [hop][Ntot]
+    float* d_E2 = nullptr;         // [hop/2][Ntot], mirrored form
     __bf16* d_Et = nullptr;        // [3][Ntot][hop] hi/mid/lo bf16 planes of E^T (split-bf16 GEMM), built on first use
     int* d_tile_group = nullptr;   // [n_tiles]
     long long* d_tile_s = nullptr; // [n_tiles] window begin of the tile's group relative to the buffer end
@@ -100,6 +101,7 @@ struct BlockDftTables {
 void free_blockdft_tables(BlockDftTables* t) {
     if (!t) return;
     if (t->d_E) (void)hipFree(t->d_E);
+    if (t->d_E2) (void)hipFree(t->d_E2);
     if (t->d_Et) (void)hipFree(t->d_Et);
     if (t->d_tile_group) (void)hipFree(t->d_tile_group);
     if (t->d_tile_s) (void)hipFree(t->d_tile_s);
@@ -251,7 +253,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct GemmTreeArgs {
     const float* pcm_base;
     unsigned pcm_bytes;
-    const float* E;
+    const float* E2;          // [K/2][Ntot]: per 64-float tile 32 cosine columns, then the 32 -sine columns (fp32 form)
     int ld;                   // Ntot
     float2* X;                // frame-tile blocked: X[((frame / 64) * xcp + col) * 64 + frame % 64]
     int xcp;                  // columns per frame tile (incl. the zeroed pad columns)
@@ -408,15 +410,25 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     }
 }
 
+// fp32 MFMA form.  The hop DFT is evaluated about the centre of the hop block: with u_m = m - (K-1)/2,
+//     P'[j][c] = sum_{m < K/2} (x[m] + x[K-1-m]) cos(th_c u_m)  +  i sum_{m < K/2} (x[m] - x[K-1-m]) (-sin(th_c u_m))
+// (cos is even, sin odd about the centre), i.e. two real GEMMs of depth K/2 — the real parts from the mirrored sums,
+// the imaginary parts from the mirrored differences — instead of one of depth K: half the MFMA work, exactly.
+// P = rho_c P' with rho_c = e^{-i th_c (K-1)/2}; the tree is linear per column, so X = rho_c X' and the constant
+// phase is folded into the kernel-product coefficients on the host (prepare_blockdft).  E2 holds, per 64-float
+// column tile, 32 cosine columns then the 32 matching -sine columns; wave column 0 multiplies the sums by the
+// former, wave column 1 the differences by the latter.  The sums / differences are formed while staging.
 template <int BM>   // rows of hop blocks per tile; 2 * BM threads (wave tile 64 x 32)
-__global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(GemmTreeArgs a) {
+__global__ __launch_bounds__(2 * BM, BM == 128 ? 3 : 2) void blockdft_gemm_tree(GemmTreeArgs a) {
     constexpr int THREADS = 2 * BM;
-    constexpr int STAGE_FLOATS = 2 * BM * (FT_BK + 1) + 16 + 2 * FT_BK * FT_BN;
+    constexpr int LDA = FT_BK + 1;
+    constexpr int A_FLOATS = 2 * 2 * BM * LDA;   // [buf][sum / difference][BM][17]
+    constexpr int STAGE_FLOATS = A_FLOATS + 16 + 2 * FT_BK * FT_BN;
     constexpr int P_FLOATS = BM * FT_LDP * 2;
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > P_FLOATS ? STAGE_FLOATS : P_FLOATS];  // staging buffers, then the P tile
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
-    float (*As)[BM][FT_BK + 1] = reinterpret_cast<float (*)[BM][FT_BK + 1]>(smem);                          // [2][BM][17]
-    float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + 2 * BM * (FT_BK + 1) + 16);  // [2][16][64], 16-B aligned
+    float (*As)[2][BM][LDA] = reinterpret_cast<float (*)[2][BM][LDA]>(smem);
+    float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + A_FLOATS + 16);  // [2][16][64], 16-B aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FusedTile T = fused_tile<BM>(a);
     const BlockGroup& G = T.G;
@@ -427,16 +439,18 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
     const long long s = a.base + G.s_rel;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
 
-    constexpr int A_PER = BM * FT_BK / THREADS;         // 8
+    constexpr int A_PER = BM * FT_BK / THREADS;         // 8 rows per thread and k-step, a front and a back sample each
     constexpr int A_ROWS_PER_PASS = THREADS / FT_BK;    // 16 / 32
-    float ra[A_PER];
+    float rf[A_PER], rk[A_PER];
     float4 rb;
     const int a_row = tid / FT_BK, a_col = tid % FT_BK;
-    const bool stages_b = BM == 128 || tid < 256;       // the 16 x 64 E tile: 256 float4
+    const bool stages_b = BM == 128 || tid < 256;       // the 16 x 64 E2 tile: 256 float4
     const int b_row = ((tid & 255) * 4) / FT_BN, b_col = ((tid & 255) * 4) % FT_BN;
+    // byte offsets of x[a_col] and x[K - 1 - a_col] of row f0 + a_row (indices before the stream wrap to huge offsets -> 0)
     const unsigned a_off0 = (unsigned)((s + (long long)(f0 + a_row) * a.K + a_col) * 4ll);
+    const unsigned a_offb = (unsigned)((s + (long long)(f0 + a_row) * a.K + (a.K - 1 - a_col)) * 4ll);
     const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
-    const float* e_ptr = a.E + (size_t)b_row * a.ld + (size_t)nt * FT_BN + b_col;
+    const float* e_ptr = a.E2 + (size_t)b_row * a.ld + (size_t)nt * FT_BN + b_col;
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -446,16 +460,23 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
     }
 #define PVQ_FT_LOAD(k0)                                                                                          \
     {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) ra[i] = __builtin_bit_cast(                            \
-            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                      \
+            rf[i] = __builtin_bit_cast(                                                                          \
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
+            rk[i] = __builtin_bit_cast(                                                                          \
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_offb + (unsigned)i * a_pass - (unsigned)(k0)*4u, 0, 0)); \
+        }                                                                                                        \
         if (stages_b) rb = *reinterpret_cast<const float4*>(e_ptr + (size_t)(k0) * a.ld);                       \
     }
 #define PVQ_FT_STORE(buf)                                                                                        \
     {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) As[buf][a_row + i * A_ROWS_PER_PASS][a_col] = ra[i];   \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                      \
+            As[buf][0][a_row + i * A_ROWS_PER_PASS][a_col] = rf[i] + rk[i];                                      \
+            As[buf][1][a_row + i * A_ROWS_PER_PASS][a_col] = rf[i] - rk[i];                                      \
+        }                                                                                                        \
         if (stages_b) *reinterpret_cast<float4*>(&Bs[buf][b_row][b_col]) = rb;                                  \
     }
-    const int n_iter = a.K / FT_BK;
+    const int n_iter = (a.K / 2) / FT_BK;
     PVQ_FT_LOAD(0);
     PVQ_FT_STORE(0);
     __syncthreads();
@@ -465,8 +486,8 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
         if (it + 1 < n_iter) PVQ_FT_LOAD((it + 1) * FT_BK);
 #pragma unroll
         for (int kk = 0; kk < FT_BK / 2; ++kk) {
-            const float a0 = As[buf][ar][2 * kk + kh];
-            const float a1 = As[buf][ar + 32][2 * kk + kh];
+            const float a0 = As[buf][wn][ar][2 * kk + kh];
+            const float a1 = As[buf][wn][ar + 32][2 * kk + kh];
             const float b = Bs[buf][2 * kk + kh][bc];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
@@ -476,12 +497,14 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
     }
 #undef PVQ_FT_LOAD
 #undef PVQ_FT_STORE
-    // P tile -> LDS as [row][66 floats] = [row][32 complex + pad]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
+    // P' tile -> LDS as [row][32 complex + pad]: wave column 0 holds the real parts, 1 the imaginary parts
+    // (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
+    const int pc = 2 * (lane & 31) + wn;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        smem[row * (2 * FT_LDP) + bc] = acc0[q];
-        smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
+        smem[row * (2 * FT_LDP) + pc] = acc0[q];
+        smem[(row + 32) * (2 * FT_LDP) + pc] = acc1[q];
     }
     __syncthreads();
     fused_tree_store<BM>(smem, tw_lds, T, a, tid);
@@ -1154,21 +1177,42 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     t->n_tiles = tile;
     const int ntot = tile * GM_BN;
     auto tq = [&](double v) { const float f = (float)v; return twiddle_fp16_ ? round_to_half(f) : f; };   // config 4: fp16 twiddles
+    // The hop DFT is taken about the centre of the hop block (see blockdft_gemm_tree): E[m][c] = e^{-i th_c u_m},
+    // u_m = m - (hop-1)/2, th_c = 2 pi c / W.  Every GEMM form therefore yields P' = P / rho_c, rho_c = e^{-i th_c (hop-1)/2},
+    // and the tree X' = X / rho_c; rho_c goes into the kernel-product coefficients below.
+    //   E  [hop][Ntot]   : (cos, sin) interleaved per column — unfused GEMM and the split-bf16 planes
+    //   E2 [hop/2][Ntot] : per 64-float tile 32 cosines, then the 32 sines of the same columns — the mirrored fp32 form
     std::vector<float> E((size_t)hop * ntot, 0.0f);
+    std::vector<float> E2((size_t)(hop / 2) * ntot, 0.0f);
+    std::vector<std::vector<std::pair<double, double>>> rho(groups.size());
     std::vector<int> tile_group(tile);
     std::vector<float2> comb_tw((size_t)std::max(tw_off, 1), make_float2(0.0f, 0.0f));
     for (size_t g = 0; g < groups.size(); ++g) {
         const BlockGroup& B = t->groups[g];
         const double W = (double)groups[g].window_size();
+        const long long W2 = 2ll * (long long)groups[g].window_size();
         for (int tt = 0; tt < B.n_tiles; ++tt) tile_group[B.tile0 + tt] = (int)g;
+        rho[g].resize(B.n_cols);
         for (int ci = 0; ci < B.n_cols; ++ci) {
             const long long c = (long long)col_of[g][ci];  // actual spectrum column
+            {
+                const long long prod = (c * (long long)(hop - 1)) % W2;
+                const double ang = -2.0 * pi * (double)prod / (double)W2;
+                rho[g][ci] = {std::cos(ang), std::sin(ang)};
+            }
             for (size_t m = 0; m < hop; ++m) {
-                // reduce the angle exactly: (c*m) mod W in integers
-                const long long prod = (c * (long long)m) % (long long)W;
-                const double ang = -2.0 * pi * (double)prod / W;
-                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci] = tq(std::cos(ang));
-                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci + 1] = tq(std::sin(ang));
+                // reduce the angle exactly: c * (2m - hop + 1) mod 2W in integers
+                long long prod = (c * (2ll * (long long)m - (long long)hop + 1ll)) % W2;
+                if (prod < 0) prod += W2;
+                const double ang = -2.0 * pi * (double)prod / (double)W2;
+                const float er = tq(std::cos(ang)), ei = tq(std::sin(ang));
+                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci] = er;
+                E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci + 1] = ei;
+                if (m < hop / 2) {
+                    const size_t o = m * ntot + (size_t)(B.tile0 + ci / CB_C) * GM_BN + (size_t)(ci % CB_C);
+                    E2[o] = er;
+                    E2[o + CB_C] = ei;
+                }
             }
             for (int l = 0; l < B.levels; ++l) {
                 const long long prod = (c * (1ll << l)) % (long long)B.nb;
@@ -1176,12 +1220,14 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                 comb_tw[B.tw_off + l * (B.n_tiles * CB_C) + ci] = make_float2(tq(std::cos(ang)), tq(std::sin(ang)));
             }
         }
+        (void)W;
     }
     // Banded kernel product tables: per window group, blocks of BD_RB consecutive bins; a block walks the
     // union of its rows' (compressed) columns.  B operand of column c, lane l (n = l & 31, k = l >> 5):
     // output n = part * 16 + row, k = 0 multiplies Re X, k = 1 multiplies Im X:
     //     y += v X        : re += vr Xr - vi Xi,  im += vi Xr + vr Xi      (filter_bank, vqt.rs:889-895)
     //     y += conj(w X)  : re += wr Xr - wi Xi,  im += -wi Xr - wr Xi     (negative_filter_bank, vqt.rs:896-910)
+    // with v, w the reference's coefficients times rho_c (the GEMM stages deliver X' = X / rho_c, see above).
     const int nb = (int)n_bins();
     t->n_bins_pad = (nb + 63) / 64 * 64;
     std::vector<BandBlock> band;
@@ -1221,8 +1267,12 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
             for (uint32_t r = r0; r < r1; ++r) {
                 const int row = (int)(r - r0);
                 for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
-                    const int cc = idx_of[g][A.col_idx[q]] - lo;
-                    const float vr = A.values[q].re, vi = A.values[q].im;
+                    const int ci = idx_of[g][A.col_idx[q]];
+                    const int cc = ci - lo;
+                    // v * rho_c, in double, rounded once
+                    const double ar_ = A.values[q].re, ai_ = A.values[q].im;
+                    const float vr = (float)(ar_ * rho[g][ci].first - ai_ * rho[g][ci].second);
+                    const float vi = (float)(ar_ * rho[g][ci].second + ai_ * rho[g][ci].first);
                     at(Bp, cc, 0 * 32 + row) += vr;        // k = 0 (Re X) -> re
                     at(Bp, cc, 1 * 32 + row) += -vi;       // k = 1 (Im X) -> re
                     at(Bp, cc, 0 * 32 + 16 + row) += vi;   // k = 0 -> im
@@ -1230,8 +1280,11 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                 }
                 if (Bm.nnz() > 0)
                     for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
-                        const int cc = idx_of[g][Bm.col_idx[q]] - lo;
-                        const float wr = Bm.values[q].re, wi = Bm.values[q].im;
+                        const int ci = idx_of[g][Bm.col_idx[q]];
+                        const int cc = ci - lo;
+                        const double br_ = Bm.values[q].re, bi_ = Bm.values[q].im;
+                        const float wr = (float)(br_ * rho[g][ci].first - bi_ * rho[g][ci].second);
+                        const float wi = (float)(br_ * rho[g][ci].second + bi_ * rho[g][ci].first);
                         at(Bp, cc, 0 * 32 + row) += wr;
                         at(Bp, cc, 1 * 32 + row) += -wi;
                         at(Bp, cc, 0 * 32 + 16 + row) += -wi;
@@ -1286,7 +1339,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     for (size_t g = 0; g < groups.size(); ++g)
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
     t->h_E = E;  // kept for the lazily built bf16 planes
-    bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
+    bool ok = up(&t->d_E, E) && up(&t->d_E2, E2) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3);
     if (!ok) {
@@ -1322,7 +1375,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     }
     const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
     static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
-    const bool fused = fuse_env && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : FT_BK) == 0;
+    const bool fused = fuse_env && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 2 * FT_BK) == 0;
     if (!fused) {
         const size_t p_bytes = rows_cap * ntot * sizeof(float);
         if (t->p_cap < p_bytes) {
@@ -1368,7 +1421,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             GemmTreeArgs fa;
             fa.pcm_base = pcm_base;
             fa.pcm_bytes = pcm_bytes;
-            fa.E = t->d_E;
+            fa.E2 = t->d_E2;
             fa.ld = ntot;
             fa.X = X;
             fa.xcp = xcp;
