@@ -81,7 +81,6 @@ struct BlockDftTables {
     std::vector<BlockGroup> groups;
     std::vector<float> h_E;        // host copy of E
     float* d_E = nullptr;          // [hop][Ntot]
-    float* d_E2 = nullptr;         // [hop/2][Ntot], mirrored form
     __bf16* d_Et = nullptr;        // [3][Ntot][hop] hi/mid/lo bf16 planes of E^T (split-bf16 GEMM), built on first use
     int* d_tile_group = nullptr;   // [n_tiles]
     long long* d_tile_s = nullptr; // [n_tiles] window begin of the tile's group relative to the buffer end
@@ -101,7 +100,6 @@ struct BlockDftTables {
 void free_blockdft_tables(BlockDftTables* t) {
     if (!t) return;
     if (t->d_E) (void)hipFree(t->d_E);
-    if (t->d_E2) (void)hipFree(t->d_E2);
     if (t->d_Et) (void)hipFree(t->d_Et);
     if (t->d_tile_group) (void)hipFree(t->d_tile_group);
     if (t->d_tile_s) (void)hipFree(t->d_tile_s);
@@ -253,7 +251,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct GemmTreeArgs {
     const float* pcm_base;
     unsigned pcm_bytes;
-    const float* E2;          // [K/2][Ntot]: per 64-float tile 32 cosine columns, then the 32 -sine columns (fp32 form)
+    const float* E;           // [K][Ntot], (cos, sin) of e^{-i th_c u_m} interleaved per column; the fp32 form reads rows m < K/2
     int ld;                   // Ntot
     float2* X;                // frame-tile blocked: X[((frame / 64) * xcp + col) * 64 + frame % 64]
     int xcp;                  // columns per frame tile (incl. the zeroed pad columns)
@@ -265,9 +263,12 @@ struct GemmTreeArgs {
     const BlockGroup* groups;
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
+    unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][4] 100 MHz clock at start / after K loop / after tree / end
 };
+#define PVQ_STAMP(i) \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 4 + (i)] = wall_clock64();
 
-constexpr int FT_BM = 128, FT_BN = 64, FT_BK = 16;
+constexpr int FT_BM = 128, FT_BN = 64;
 
 // which (group, row tile, column tile) a workgroup of the fused kernels owns
 struct FusedTile {
@@ -400,6 +401,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
         }
         __syncthreads();
     }
+    PVQ_STAMP(2);
     // lanes walk the frames of one column: 512-byte runs in memory, conflict-free LDS reads
     const int j = tid & (BM - 1);
     const int f = t.f0 + j;
@@ -408,6 +410,11 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
 #pragma unroll 4
         for (int cc = tid / BM; cc < CB_C; cc += 2) dst[cc * 64] = A[j][cc];
     }
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);   // stores issued and acknowledged
+        __syncthreads();
+        PVQ_STAMP(3);
+    }
 }
 
 // fp32 MFMA form.  The hop DFT is evaluated about the centre of the hop block: with u_m = m - (K-1)/2,
@@ -415,96 +422,124 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
 // (cos is even, sin odd about the centre), i.e. two real GEMMs of depth K/2 — the real parts from the mirrored sums,
 // the imaginary parts from the mirrored differences — instead of one of depth K: half the MFMA work, exactly.
 // P = rho_c P' with rho_c = e^{-i th_c (K-1)/2}; the tree is linear per column, so X = rho_c X' and the constant
-// phase is folded into the kernel-product coefficients on the host (prepare_blockdft).  E2 holds, per 64-float
-// column tile, 32 cosine columns then the 32 matching -sine columns; wave column 0 multiplies the sums by the
-// former, wave column 1 the differences by the latter.  The sums / differences are formed while staging.
-template <int BM>   // rows of hop blocks per tile; 2 * BM threads (wave tile 64 x 32)
-__global__ __launch_bounds__(2 * BM, BM == 128 ? 3 : 2) void blockdft_gemm_tree(GemmTreeArgs a) {
+// phase is folded into the kernel-product coefficients on the host (prepare_blockdft).
+//
+// The PCM matrix goes from memory straight into MFMA operand registers, no LDS staging and no barrier in the K loop:
+// a wave owns 32 block rows x all 32 complex columns of the tile; lane (row = lane & 31, half = lane >> 5) fetches
+// the 16 consecutive samples k0 + 16 half .. + 15 of its row and the 16 mirrored ones (64-byte runs: every cache line
+// it touches is consumed by four back-to-back loads), forms the 16 sums and 16 differences in registers, and these
+// ARE the A operands of 16 v_mfma_f32_32x32x2_f32 pairs (k order within a stage: k0 + 16 half + t; any order works
+// as long as the B rows follow it).  acc0 += sums x cosines, acc1 += differences x (-sines).  The tile's slice of E
+// (rows m < K/2, (cos, -sin) interleaved) is staged into LDS once per 128 rows of K/2 and read as one b64 per pair.
+constexpr int FR_KC = 128;   // rows of E staged per pass (32 KB)
+// idx_f / idx_b: sample index (relative to pcm_base) of the lane's front run and of its mirrored run
+template <bool VEC>
+__device__ __forceinline__ void fused_f32_stage_load(const i32x4& rsrc4, __amdgpu_buffer_rsrc_t rsrc, long long idx_f, long long idx_b,
+                                                     float (&fr)[16], float (&bk)[16]) {
+    if (VEC) {   // the whole tile lies inside the stream: offsets are plain non-negative byte offsets
+        const unsigned off_f = (unsigned)(idx_f * 4ll), off_b = (unsigned)(idx_b * 4ll);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)(off_f + 16u * q), 0, 0);
+            const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)(off_b + 16u * q), 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fr[4 * q + i] = v[i];
+                bk[4 * q + i] = w[i];
+            }
+        }
+    } else {
+        // tiles that touch the stream start / end: samples before the stream get an explicit out-of-range offset
+        // (a wrapped negative offset plus the instruction's immediate offset would not wrap in the hardware's range
+        // check), samples past the end are zeroed by the range check itself
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long long jf = idx_f + q, jb = idx_b + q;
+            const unsigned of = jf >= 0 ? (unsigned)(jf * 4ll) : 0xFFFFFFFCu;
+            const unsigned ob = jb >= 0 ? (unsigned)(jb * 4ll) : 0xFFFFFFFCu;
+            fr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, of, 0, 0));
+            bk[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ob, 0, 0));
+        }
+    }
+}
+
+template <bool VEC, int BM>
+__device__ __forceinline__ void fused_f32_kloop(const GemmTreeArgs& a, float* smem, long long idx_f0, long long idx_b0, const float* e_tile,
+                                                int tid, f32x16& acc0, f32x16& acc1) {
     constexpr int THREADS = 2 * BM;
-    constexpr int LDA = FT_BK + 1;
-    constexpr int A_FLOATS = 2 * 2 * BM * LDA;   // [buf][sum / difference][BM][17]
-    constexpr int STAGE_FLOATS = A_FLOATS + 16 + 2 * FT_BK * FT_BN;
+    const int lane = tid & 63;
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+    const int K2 = a.K / 2;
+    const float2* bsl = reinterpret_cast<const float2*>(smem) + (lane >> 5) * 16 * CB_C + (lane & 31);   // row 16 half, column lane & 31
+    float fr[16], bk[16];
+    for (int kc = 0; kc < K2; kc += FR_KC) {
+        const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
+        fused_f32_stage_load<VEC>(rsrc4, rsrc, idx_f0 + kc, idx_b0 - kc, fr, bk);
+        if (kc > 0) __syncthreads();   // every wave is done with the previous slice
+        for (int i = tid; i < rows * (FT_BN / 4); i += THREADS) {
+            const int r = i / (FT_BN / 4), c4 = i % (FT_BN / 4);
+            *reinterpret_cast<float4*>(smem + r * FT_BN + c4 * 4) = *reinterpret_cast<const float4*>(e_tile + (size_t)(kc + r) * a.ld + c4 * 4);
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < rows; k0 += 32) {
+            float sm[16], df[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                sm[t] = fr[t] + bk[15 - t];
+                df[t] = fr[t] - bk[15 - t];
+            }
+            if (k0 + 32 < rows)
+                fused_f32_stage_load<VEC>(rsrc4, rsrc, idx_f0 + (kc + k0 + 32), idx_b0 - (kc + k0 + 32), fr, bk);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float2 b = bsl[(k0 + t) * CB_C];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sm[t], b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(df[t], b.y, acc1, 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int BM>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 complex columns
+__global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(GemmTreeArgs a) {
+    constexpr int B_FLOATS = FR_KC * FT_BN;
     constexpr int P_FLOATS = BM * FT_LDP * 2;
-    __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > P_FLOATS ? STAGE_FLOATS : P_FLOATS];  // staging buffers, then the P tile
+    __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice, then the P tile
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
-    float (*As)[2][BM][LDA] = reinterpret_cast<float (*)[2][BM][LDA]>(smem);
-    float (*Bs)[FT_BK][FT_BN] = reinterpret_cast<float (*)[FT_BK][FT_BN]>(smem + A_FLOATS + 16);  // [2][16][64], 16-B aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FusedTile T = fused_tile<BM>(a);
-    const BlockGroup& G = T.G;
     const int f0 = T.f0, nt = T.nt;
     if (f0 >= a.n_frames) return;
+    PVQ_STAMP(0);
     if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
-    const int wm = wave >> 1, wn = wave & 1;
-    const long long s = a.base + G.s_rel;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
-
-    constexpr int A_PER = BM * FT_BK / THREADS;         // 8 rows per thread and k-step, a front and a back sample each
-    constexpr int A_ROWS_PER_PASS = THREADS / FT_BK;    // 16 / 32
-    float rf[A_PER], rk[A_PER];
-    float4 rb;
-    const int a_row = tid / FT_BK, a_col = tid % FT_BK;
-    const bool stages_b = BM == 128 || tid < 256;       // the 16 x 64 E2 tile: 256 float4
-    const int b_row = ((tid & 255) * 4) / FT_BN, b_col = ((tid & 255) * 4) % FT_BN;
-    // byte offsets of x[a_col] and x[K - 1 - a_col] of row f0 + a_row (indices before the stream wrap to huge offsets -> 0)
-    const unsigned a_off0 = (unsigned)((s + (long long)(f0 + a_row) * a.K + a_col) * 4ll);
-    const unsigned a_offb = (unsigned)((s + (long long)(f0 + a_row) * a.K + (a.K - 1 - a_col)) * 4ll);
-    const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
-    const float* e_ptr = a.E2 + (size_t)b_row * a.ld + (size_t)nt * FT_BN + b_col;
-
+    const long long s = a.base + T.G.s_rel;
+    const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
+    const long long row0 = tile_lo + (long long)(wave * 32 + (lane & 31)) * a.K;
+    const int half = lane >> 5;
+    // the lane's front run x[16 half .. +15] and its mirror x[K - 16 - 16 half .. +15] (stage 0)
+    const long long off_f0 = row0 + 16 * half;
+    const long long off_b0 = row0 + a.K - 16 - 16 * half;
+    const float* e_tile = a.E + (size_t)nt * FT_BN;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         acc0[q] = 0.0f;
         acc1[q] = 0.0f;
     }
-#define PVQ_FT_LOAD(k0)                                                                                          \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                      \
-            rf[i] = __builtin_bit_cast(                                                                          \
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
-            rk[i] = __builtin_bit_cast(                                                                          \
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_offb + (unsigned)i * a_pass - (unsigned)(k0)*4u, 0, 0)); \
-        }                                                                                                        \
-        if (stages_b) rb = *reinterpret_cast<const float4*>(e_ptr + (size_t)(k0) * a.ld);                       \
-    }
-#define PVQ_FT_STORE(buf)                                                                                        \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                      \
-            As[buf][0][a_row + i * A_ROWS_PER_PASS][a_col] = rf[i] + rk[i];                                      \
-            As[buf][1][a_row + i * A_ROWS_PER_PASS][a_col] = rf[i] - rk[i];                                      \
-        }                                                                                                        \
-        if (stages_b) *reinterpret_cast<float4*>(&Bs[buf][b_row][b_col]) = rb;                                  \
-    }
-    const int n_iter = (a.K / 2) / FT_BK;
-    PVQ_FT_LOAD(0);
-    PVQ_FT_STORE(0);
-    __syncthreads();
-    const int ar = wm * 64 + (lane & 31), kh = lane >> 5, bc = wn * 32 + (lane & 31);
-    for (int it = 0; it < n_iter; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < n_iter) PVQ_FT_LOAD((it + 1) * FT_BK);
-#pragma unroll
-        for (int kk = 0; kk < FT_BK / 2; ++kk) {
-            const float a0 = As[buf][wn][ar][2 * kk + kh];
-            const float a1 = As[buf][wn][ar + 32][2 * kk + kh];
-            const float b = Bs[buf][2 * kk + kh][bc];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
-        }
-        if (it + 1 < n_iter) PVQ_FT_STORE(buf ^ 1);
-        __syncthreads();
-    }
-#undef PVQ_FT_LOAD
-#undef PVQ_FT_STORE
-    // P' tile -> LDS as [row][32 complex + pad]: wave column 0 holds the real parts, 1 the imaginary parts
-    // (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
-    const int pc = 2 * (lane & 31) + wn;
+    if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
+        fused_f32_kloop<true, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+    else
+        fused_f32_kloop<false, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+    PVQ_STAMP(1);
+    __syncthreads();   // the E slice is dead: the P' tile takes its place
+    // P' tile -> LDS as [row][32 complex + pad]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
+    float2 (*Pt)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int row = wm * 64 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        smem[row * (2 * FT_LDP) + pc] = acc0[q];
-        smem[(row + 32) * (2 * FT_LDP) + pc] = acc1[q];
+        const int row = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        Pt[row][lane & 31] = make_float2(acc0[q], acc1[q]);
     }
     __syncthreads();
     fused_tree_store<BM>(smem, tw_lds, T, a, tid);
@@ -537,7 +572,7 @@ __device__ __forceinline__ int fb_off(int row, int ch) { return row * FB_BK + ((
 // thread's 16 consecutive samples come as four 16-byte loads; otherwise (tiles that touch the stream start
 // or end) as 16 dword loads, each range-checked by the buffer hardware.
 template <bool VEC, int BM>
-__device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsigned char* smem_raw, unsigned a_off0, const __bf16* e_ptr,
+__device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsigned char* smem_raw, long long a_idx0, const __bf16* e_ptr,
                                                    int tid, f32x16& acc0, f32x16& acc1) {
     constexpr int FB_PLANE = FbGeom<BM>::PLANE;
     __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
@@ -554,7 +589,7 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)(a_off0 + (unsigned)k0 * 4u + 16u * q), 0, 0);
+                const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)(a_idx0 * 4ll) + (unsigned)k0 * 4u + 16u * q), 0, 0);
                 ra[4 * q + 0] = v[0];
                 ra[4 * q + 1] = v[1];
                 ra[4 * q + 2] = v[2];
@@ -562,8 +597,10 @@ __device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsign
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)k0 * 4u + 4u * q, 0, 0));
+            for (int q = 0; q < 16; ++q) {   // samples before the stream: an explicit out-of-range offset (see fused_f32_stage_load)
+                const long long j = a_idx0 + k0 + q;
+                ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, j >= 0 ? (unsigned)(j * 4ll) : 0xFFFFFFFCu, 0, 0));
+            }
         }
         if (BM == 128 || tid < 256) {
 #pragma unroll
@@ -642,7 +679,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
     const int wm = wave >> 1, wn = wave & 1;
     const long long s = a.base + T.G.s_rel;
     const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
-    const unsigned a_off0 = (unsigned)((tile_lo + (long long)(tid >> 1) * a.K + (tid & 1) * 16) * 4ll);
+    const long long a_off0 = tile_lo + (long long)(tid >> 1) * a.K + (tid & 1) * 16;   // sample index of the thread's 16-sample run
     const __bf16* e_ptr = a.Et + (size_t)(nt * FT_BN + ((tid & 255) >> 2)) * a.K + (tid & 3) * 8;
     f32x16 acc0, acc1;
 #pragma unroll
@@ -1180,10 +1217,8 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     // The hop DFT is taken about the centre of the hop block (see blockdft_gemm_tree): E[m][c] = e^{-i th_c u_m},
     // u_m = m - (hop-1)/2, th_c = 2 pi c / W.  Every GEMM form therefore yields P' = P / rho_c, rho_c = e^{-i th_c (hop-1)/2},
     // and the tree X' = X / rho_c; rho_c goes into the kernel-product coefficients below.
-    //   E  [hop][Ntot]   : (cos, sin) interleaved per column — unfused GEMM and the split-bf16 planes
-    //   E2 [hop/2][Ntot] : per 64-float tile 32 cosines, then the 32 sines of the same columns — the mirrored fp32 form
+    //   E [hop][Ntot], (cos, sin) interleaved per column; the mirrored fp32 form reads its first hop/2 rows
     std::vector<float> E((size_t)hop * ntot, 0.0f);
-    std::vector<float> E2((size_t)(hop / 2) * ntot, 0.0f);
     std::vector<std::vector<std::pair<double, double>>> rho(groups.size());
     std::vector<int> tile_group(tile);
     std::vector<float2> comb_tw((size_t)std::max(tw_off, 1), make_float2(0.0f, 0.0f));
@@ -1208,11 +1243,6 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                 const float er = tq(std::cos(ang)), ei = tq(std::sin(ang));
                 E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci] = er;
                 E[m * ntot + (size_t)B.tile0 * GM_BN + 2 * ci + 1] = ei;
-                if (m < hop / 2) {
-                    const size_t o = m * ntot + (size_t)(B.tile0 + ci / CB_C) * GM_BN + (size_t)(ci % CB_C);
-                    E2[o] = er;
-                    E2[o + CB_C] = ei;
-                }
             }
             for (int l = 0; l < B.levels; ++l) {
                 const long long prod = (c * (1ll << l)) % (long long)B.nb;
@@ -1339,7 +1369,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     for (size_t g = 0; g < groups.size(); ++g)
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
     t->h_E = E;  // kept for the lazily built bf16 planes
-    bool ok = up(&t->d_E, E) && up(&t->d_E2, E2) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
+    bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3);
     if (!ok) {
@@ -1375,7 +1405,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     }
     const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
     static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
-    const bool fused = fuse_env && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 2 * FT_BK) == 0;
+    const bool fused = fuse_env && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
     if (!fused) {
         const size_t p_bytes = rows_cap * ntot * sizeof(float);
         if (t->p_cap < p_bytes) {
@@ -1421,7 +1451,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             GemmTreeArgs fa;
             fa.pcm_base = pcm_base;
             fa.pcm_bytes = pcm_bytes;
-            fa.E2 = t->d_E2;
+            fa.E = t->d_E;
             fa.ld = ntot;
             fa.X = X;
             fa.xcp = xcp;
@@ -1444,6 +1474,12 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
             fa.Et = t->d_Et;
+            static const char* stamps_env = getenv("PVQ_STAMPS");   // developer knob: dump per-workgroup phase stamps once
+            static bool stamps_done = false;
+            const bool do_stamps = stamps_env && !stamps_done;
+            fa.stamps = nullptr;
+            if (do_stamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&fa.stamps), (size_t)off * 4 * 8 + 8));
+            if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 4 * 8 + 8));
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
             if (use_bf && fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
@@ -1454,6 +1490,17 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             else
                 hipLaunchKernelGGL(blockdft_gemm_tree<128>, dim3(off), dim3(256), 0, stream, fa);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
+            if (do_stamps) {
+                stamps_done = true;
+                std::vector<unsigned long long> h((size_t)off * 4);
+                PVQ_HIP(hipStreamSynchronize(stream));
+                PVQ_HIP(hipMemcpy(h.data(), fa.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+                PVQ_HIP(hipFree(fa.stamps));
+                if (FILE* fp = fopen(stamps_env, "wb")) {
+                    fwrite(h.data(), 8, h.size(), fp);
+                    fclose(fp);
+                }
+            }
         } else {
             const int n_rows = (int)(nf + t->nb_max - 1);
             GemmArgs ga;

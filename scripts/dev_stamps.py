@@ -1,0 +1,30 @@
+"""Phase stamps of the fused GEMM + tree kernel (developer tool): PVQ_STAMPS dump -> per-phase percentiles."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "stamps.bin")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+os.environ["PVQ_STAMPS"] = out
+import numpy as np, torch
+import __graft_entry__ as g; g.build()
+import pitchvis_amd as P
+pp = P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 7, 36))
+v = P.Vqt(pp, 0); v.set_algo(2)
+if len(sys.argv) > 1: v.set_gemm_precision(int(sys.argv[1]))
+hop, nf = 256, 65536
+d_pcm = (torch.rand(hop*nf, device="cuda") - 0.5) * 0.5
+d_db = torch.empty((nf, v.n_bins), device="cuda")
+v.calculate_batch_db_device(d_pcm, hop, nf, d_db); torch.cuda.synchronize()   # the knob fires on the first launch
+s = np.fromfile(out, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
+s = s[s[:, 0] > 0]
+t0 = s[:, 0].min()
+tick = 10e-3  # us per tick (100 MHz)
+k, tr, st = (s[:, 1]-s[:, 0])*tick, (s[:, 2]-s[:, 1])*tick, (s[:, 3]-s[:, 2])*tick
+life = (s[:, 3]-s[:, 0])*tick
+print(f"workgroups {len(s)}  span {(s[:,3].max()-t0)*tick:.1f} us")
+for name, a in (("k loop", k), ("tree", tr), ("store", st), ("life", life)):
+    print(f"{name:7s} p10 {np.percentile(a,10):7.2f}  p50 {np.percentile(a,50):7.2f}  p90 {np.percentile(a,90):7.2f}  mean {a.mean():7.2f} us")
+# by fifths of the block index (groups are laid out one after the other: Nb = 64, 32, 16, 8, 4)
+n = len(s)
+for q in range(5):
+    sl = slice(q*n//5, (q+1)*n//5)
+    print(f"blocks {q*n//5:5d}..{(q+1)*n//5:5d}: k {np.median(k[sl]):6.2f}  tree {np.median(tr[sl]):6.2f}  store {np.median(st[sl]):6.2f}  start {np.median(s[sl,0]-t0)*tick:7.1f} us")
