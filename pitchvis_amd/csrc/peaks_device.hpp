@@ -363,10 +363,18 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
 // on the minimum of the samples met before the first higher one.  4 VALU + 1 LDS read per step, no
 // masks, two independent chains (left / right).  A lane whose window ends without a decision
 // (no low sample, no higher sample within PK_PAD) is settled by the exact wave-cooperative test.
-// Returns false, having written nothing, when the frame contains a plateau candidate: the caller
-// then runs the generic routine.
+// Returns false, having written nothing, when the frame may contain a plateau peak of three or more samples:
+// the caller then runs the generic routine.
 // ------------------------------------------------------------------------------------------------
 constexpr int PK_PAD = 16;
+
+// bin i (value xv) is the reported position of a peak of one sample (a rise before, a fall after) or of a two-sample
+// plateau (i is its second sample: middle_position of the half-open range [i-1, i+1) is i).  x carries +INF sentinels
+// on both sides, so the frame edges never qualify.
+__device__ __forceinline__ bool pk_is_top(const float* x, int i, float xv) {
+    const float l = x[i - 1];
+    return (x[i + 1] < xv) && ((l < xv) || (l == xv && x[i - 2] < xv));
+}
 
 // LDS scratch of the lean routine besides the frame: candidate list (u16), peak list (u16), peak flags (u8)
 __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist) {
@@ -395,10 +403,12 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         const int i = (k << 6) + lane;
         v[k] = (i < n) ? x[i] : INF;
         if (i < n) fmin_ = fminf(fmin_, v[k]);
-        // a rise followed by an equal sample may start a plateau peak: leave those frames to the generic code
-        plateau |= (i >= 1 && i < n - 1) && (x[i - 1] < v[k]) && (x[i + 1] == v[k]);
+        // a rise followed by two equal samples may start a plateau peak of three or more: leave those frames to the
+        // generic code (two-sample plateaus — exact ties of neighbouring bins, a few per 10^5 noise frames — are taken
+        // here: their middle_position is the second sample)
+        plateau |= (i >= 1 && i < n - 2) && (x[i - 1] < v[k]) && (x[i + 1] == v[k]) && (x[i + 2] == v[k]);
         if (i < npad) flag[i] = 0;
-        if (DISTANCE && i < npad) lmax[i] = (i >= 1 && i < n - 1 && x[i - 1] < v[k] && x[i + 1] < v[k]) ? 1 : 0;
+        if (DISTANCE && i < npad) lmax[i] = (i >= 1 && i < n - 1 && pk_is_top(x, i, v[k])) ? 1 : 0;
     }
     if (__ballot(plateau)) return false;
     if (DISTANCE) {   // find_peaks' distance rule runs before its prominence test, once per height threshold
@@ -420,7 +430,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
         const float H = bass ? a.bass_min_height : a.peak_min_height;
         const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
-        bool pre = (i >= a.min_bin) && (i < n) && (x[i - 1] < xv) && (x[i + 1] < xv) && (xv >= H) &&
+        bool pre = (i >= a.min_bin) && (i < n) && pk_is_top(x, i, xv) && (xv >= H) &&
                    (!(P > 0.0f) || (xv - fmin_ >= P));
         if (DISTANCE && pre) pre = (bass ? keep0[i] : keep1[i]) != 0;
         const unsigned long long bm = __ballot(pre);

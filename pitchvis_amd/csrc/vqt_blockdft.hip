@@ -263,10 +263,10 @@ struct GemmTreeArgs {
     const BlockGroup* groups;
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
-    unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][4] 100 MHz clock at start / after K loop / after tree / end
+    unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
 };
 #define PVQ_STAMP(i) \
-    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 4 + (i)] = wall_clock64();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();
 
 constexpr int FT_BM = 128, FT_BN = 64;
 
@@ -302,13 +302,14 @@ __device__ __forceinline__ void fused_stage_twiddles(float2 (*tw)[CB_C], const F
     if (l < t.G.levels) tw[l][c] = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
 }
 
-// lo + w * hi with a fixed operation order (explicit fma, no further contraction): every tree level, whichever code
-// path evaluates it, rounds identically, so a frame's result does not depend on where it sits in a tile
+// lo + w * hi with a fixed operation order — (re, im) = fma((-w.y, w.y), (hi.y, hi.x), fma((w.x, w.x), (hi.x, hi.y), lo)),
+// two packed fp32 fmas (v_pk_fma_f32): every tree level, whichever code path evaluates it, rounds identically, so a
+// frame's result does not depend on where it sits in a tile
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 tree_cmadd(float2 lo, float2 w, float2 hi) {
-#pragma clang fp contract(off)
-    const float re = __builtin_fmaf(-w.y, hi.y, w.x * hi.x);
-    const float im = __builtin_fmaf(w.y, hi.x, w.x * hi.y);
-    return make_float2(lo.x + re, lo.y + im);
+    const f32x2 t = __builtin_elementwise_fma((f32x2){w.x, w.x}, (f32x2){hi.x, hi.y}, (f32x2){lo.x, lo.y});
+    const f32x2 r = __builtin_elementwise_fma((f32x2){-w.y, w.y}, (f32x2){hi.y, hi.x}, t);
+    return make_float2(r.x, r.y);
 }
 
 // the first R <= 4 tree levels (strides 1 .. 8) in registers: a thread owns 16 consecutive rows of one column and
@@ -354,6 +355,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
         case 4: fused_tree_register_levels<4, BM>(A, tw, tid); break;
         default: break;
     }
+    PVQ_STAMP(6);
     int valid = BM - ((1 << l) - 1);
     // remaining levels (strides >= 16) through LDS, two per pass where possible: evaluated exactly as two radix-2
     // levels (same operations in the same order), outputs in groups of four to bound the registers
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
         fused_f32_kloop<false, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
     PVQ_STAMP(1);
     __syncthreads();   // the E slice is dead: the P' tile takes its place
+    PVQ_STAMP(4);
     // P' tile -> LDS as [row][32 complex + pad]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
     float2 (*Pt)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);
 #pragma unroll
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
         Pt[row][lane & 31] = make_float2(acc0[q], acc1[q]);
     }
     __syncthreads();
+    PVQ_STAMP(5);
     fused_tree_store<BM>(smem, tw_lds, T, a, tid);
 }
 
@@ -1459,6 +1463,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.K = (int)hop;
             fa.base = base;
             fa.n_groups = t->n_groups;
+            static const int dyn_lds_env = getenv("PVQ_DYN_LDS") ? atoi(getenv("PVQ_DYN_LDS")) : 0;   // developer knob: extra LDS -> 1 workgroup per CU
             static const int bm_env = getenv("PVQ_FUSED_BM") ? atoi(getenv("PVQ_FUSED_BM")) : 0;   // developer knob
             // 256-row tiles for the split-bf16 form: 257 - Nb complete frames per tile (1.08x row recomputation instead
             // of 1.2x) and the E^T planes staged once per 256 rows; measured 7 % faster than 128-row tiles
@@ -1478,21 +1483,21 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             static bool stamps_done = false;
             const bool do_stamps = stamps_env && !stamps_done;
             fa.stamps = nullptr;
-            if (do_stamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&fa.stamps), (size_t)off * 4 * 8 + 8));
-            if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 4 * 8 + 8));
+            if (do_stamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&fa.stamps), (size_t)off * 8 * 8 + 8));
+            if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 8 * 8 + 8));
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
             if (use_bf && fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (use_bf)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<128>, dim3(off), dim3(256), 0, stream, fa);
             else if (fused_bm == 256)
-                hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), 0, stream, fa);
+                hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
             else
                 hipLaunchKernelGGL(blockdft_gemm_tree<128>, dim3(off), dim3(256), 0, stream, fa);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
             if (do_stamps) {
                 stamps_done = true;
-                std::vector<unsigned long long> h((size_t)off * 4);
+                std::vector<unsigned long long> h((size_t)off * 8);
                 PVQ_HIP(hipStreamSynchronize(stream));
                 PVQ_HIP(hipMemcpy(h.data(), fa.stamps, h.size() * 8, hipMemcpyDeviceToHost));
                 PVQ_HIP(hipFree(fa.stamps));

@@ -14,14 +14,15 @@ hop, nf = 256, 65536
 d_pcm = (torch.rand(hop*nf, device="cuda") - 0.5) * 0.5
 d_db = torch.empty((nf, v.n_bins), device="cuda")
 v.calculate_batch_db_device(d_pcm, hop, nf, d_db); torch.cuda.synchronize()   # the knob fires on the first launch
-s = np.fromfile(out, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
+s = np.fromfile(out, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
 s = s[s[:, 0] > 0]
 t0 = s[:, 0].min()
 tick = 10e-3  # us per tick (100 MHz)
 k, tr, st = (s[:, 1]-s[:, 0])*tick, (s[:, 2]-s[:, 1])*tick, (s[:, 3]-s[:, 2])*tick
 life = (s[:, 3]-s[:, 0])*tick
 print(f"workgroups {len(s)}  span {(s[:,3].max()-t0)*tick:.1f} us")
-for name, a in (("k loop", k), ("tree", tr), ("store", st), ("life", life)):
+sk, pw, rl, lp = (s[:, 4]-s[:, 1])*tick, (s[:, 5]-s[:, 4])*tick, (s[:, 6]-s[:, 5])*tick, (s[:, 2]-s[:, 6])*tick
+for name, a in (("k loop", k), ("tree", tr), (" skew", sk), (" Pwrite", pw), (" reglev", rl), (" ldslev", lp), ("store", st), ("life", life)):
     print(f"{name:7s} p10 {np.percentile(a,10):7.2f}  p50 {np.percentile(a,50):7.2f}  p90 {np.percentile(a,90):7.2f}  mean {a.mean():7.2f} us")
 # by fifths of the block index (groups are laid out one after the other: Nb = 64, 32, 16, 8, 4)
 n = len(s)

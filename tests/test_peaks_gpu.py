@@ -47,6 +47,33 @@ def test_peaks_bit_identical_on_same_frames(name):
         assert (np.abs(size[f, :k] - wsz) <= 2e-3 + 40.0 * ctol).all()  # up to ~40 dB/bin slope in random frames
 
 
+@pytest.mark.parametrize("name", ["bench_48k_252", "default_22k_588", "hires_96k_840"])
+def test_random_ties_two_and_three_sample_plateaus(name):
+    """Exact ties of neighbouring bins (the lean kernel takes two-sample plateaus itself, longer ones go to the
+    generic kernel): random frames with ties copied in at random places, at the frame edges and next to each other."""
+    pp, op = get_geom(name)
+    v = P.Vqt.new(pp, 0)
+    n = v.n_bins
+    rng = np.random.default_rng(17)
+    frames = np.abs(rng.normal(0, 9, (240, n))).astype(np.float32)
+    for f in range(frames.shape[0]):
+        for _ in range(rng.integers(1, 12)):
+            i = int(rng.integers(0, n - 3))
+            ln = 2 if f % 3 else int(rng.integers(2, 5))
+            frames[f, i:i + ln] = frames[f, i]
+        if f % 7 == 0:
+            frames[f, 0:2] = frames[f, 0]              # tie at the left edge
+        if f % 11 == 0:
+            frames[f, n - 2:n] = 35.0                  # tie at the right edge: never a peak
+        if f % 13 == 0:
+            frames[f, 40:42] = 30.0; frames[f, 42:44] = 31.0   # rising plateau then a plateau peak
+    mask, count, center, size = v.analyze_batch(frames, max_peaks=n)
+    for f in range(frames.shape[0]):
+        wp, wce, wsz = O.analyze_frame(frames[f], op.min_freq, op.octaves, op.buckets_per_octave)
+        assert np.array_equal(mask_to_indices(mask[f], n), wp), (name, f)
+        assert count[f] == wp.size
+
+
 def test_crafted_plateaus_edges_and_split():
     pp, op = get_geom("bench_48k_252")
     v = P.Vqt.new(pp, 0)
