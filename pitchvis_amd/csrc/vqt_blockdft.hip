@@ -90,9 +90,9 @@ struct BlockDftTables {
     struct BandBlock* d_band = nullptr;
     float* d_band_B = nullptr;     // per block and column: 64 floats in v_mfma_f32_32x32x2_f32 B-operand lane order
     __bf16* d_band_B3 = nullptr;   // per block and 8 columns: 3 planes x 64 lanes x 8 bf16 in v_mfma_f32_32x32x16_bf16 order
-    int* d_band_list = nullptr;    // [4][band_per_wave]: the blocks each wave of a workgroup walks
+    int* d_band_list = nullptr;    // [band_waves][band_per_wave]: per wave of a workgroup, the count and then the blocks it walks
     int band_per_wave = 0;
-    int band_cnt[4] = {0, 0, 0, 0};
+    int band_waves = 4;            // waves per kernel-product workgroup (8 when the 64-frame form is used)
     float* d_P = nullptr;  size_t p_cap = 0;   // workspace
     float2* d_X = nullptr; size_t x_cap = 0;
 };
@@ -798,11 +798,11 @@ struct BandArgs {
     const BandBlock* blocks;
     const float* B;
     const __bf16* B3;          // split-bf16 coefficient planes
-    const int* list;           // [4][per_wave]
+    const int* list;           // [waves][per_wave]: count, then the blocks of that wave
     int per_wave;
-    int cnt[4];
     float* out_db;             // [n_frames][n_bins]
     float2* out_cplx;          // optional
+    unsigned long long* stamps;   // developer knob PVQ_STAMPS_DOTS: [workgroup][8] 100 MHz clock: 0 start, 1 wave 0 done with its blocks, 2 all waves done, 3 end
 };
 
 #define PVQ_REF_POWER (0.3f * 0.3f)
@@ -840,9 +840,14 @@ __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 // results of one block (C layout: column n = lane & 31: bin row = n & 15, re / im = n >> 4; frame =
 // (q&3) + 8(q>>2) + 4(lane>>5)) -> |x_vqt|^2 into the LDS tile (+ the optional complex output).
 // v_permlane16_swap brings the im column's value into the re column's lane.
-template <int MT>
+// LDB: compile-time row stride of the tile (0: a.ldb) — with it every LDS address below is one base plus an immediate
+// offset; the optional complex output recomputes its addresses per block (the row stride is laundered through an
+// asm so that 32 loop-invariant 64-bit addresses are not kept live across the whole block loop).
+constexpr int BAND_LDB2 = 260;   // the 64-frame form: up to 256 bins + 4 (rows 4 apart land 16 banks apart)
+template <int MT, int LDB>
 __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, int f0, int bin0, int nrows,
                                               int lane) {
+    const int ldb = LDB ? LDB : a.ldb;
     const int n = lane & 31, kx = lane >> 5;
     const int row = n & 15, part = n >> 4;
     const bool mine = part == 0 && row < nrows;
@@ -860,13 +865,15 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                dbs[fr * a.ldb + bin] = acc[mt][q] * acc[mt][q] + im[q] * im[q];
+                dbs[fr * ldb + bin] = acc[mt][q] * acc[mt][q] + im[q] * im[q];
             }
             if (a.out_cplx) {
+                int row_stride = a.n_bins;
+                asm volatile("" : "+s"(row_stride));
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                    if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * a.n_bins + bin] = make_float2(acc[mt][q], im[q]);
+                    if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * row_stride + bin] = make_float2(acc[mt][q], im[q]);
                 }
             }
         }
@@ -876,14 +883,15 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 // power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins.  Up to 512 bins: four (two) frames at a
 // time with their dB values in registers, so the read -> log -> reduce -> rescale chains of the frames overlap
 // (the phase is latency-bound at two waves per SIMD); more bins: one frame at a time through LDS.
-template <int MT>
+template <int MT, int NW>
 __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f0, int wave, int lane) {
+    const int ldb = MT == 2 ? BAND_LDB2 : a.ldb;
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
     auto to_db = [&](float p) { return 3.01029995663981f * __log2f(fmaxf(p, PVQ_A_MIN)) - ref_db; };
     auto in_registers = [&](auto fu_c, auto nkb_c) {
         constexpr int FU = decltype(fu_c)::value, NKB = decltype(nkb_c)::value;
-        for (int fr0 = wave; fr0 < MT * 32; fr0 += 4 * FU) {
+        for (int fr0 = wave; fr0 < MT * 32; fr0 += NW * FU) {
             float d[FU][NKB], mx[FU], mn[FU];
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
@@ -893,7 +901,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
                 for (int kk = 0; kk < NKB; ++kk) {
                     const int k = lane + 64 * kk;
                     const bool in = k < a.n_bins;
-                    d[u][kk] = to_db(in ? dbs[(fr0 + 4 * u) * a.ldb + k] : 1.0f);
+                    d[u][kk] = to_db(in ? dbs[(fr0 + NW * u) * ldb + k] : 1.0f);
                     mx[u] = fmaxf(mx[u], in ? d[u][kk] : -3.40282347e+38f);
                     mn[u] = fminf(mn[u], in ? d[u][kk] : 3.40282347e+38f);
                 }
@@ -905,7 +913,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
             }
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
-                const int fr = fr0 + 4 * u;
+                const int fr = fr0 + NW * u;
                 if (f0 + fr >= a.n_frames) continue;
                 const float floor_db = mx[u] - PVQ_TOP_DB;
                 const float m2 = fmaxf(mn[u], floor_db);
@@ -927,9 +935,9 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
         in_registers(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
         return;
     }
-    for (int fr = wave; fr < MT * 32; fr += 4) {
+    for (int fr = wave; fr < MT * 32; fr += NW) {
         if (f0 + fr >= a.n_frames) break;
-        float* rowp = dbs + fr * a.ldb;
+        float* rowp = dbs + fr * ldb;
         float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
         for (int k = lane; k < a.n_bins; k += 64) {
             const float d = to_db(rowp[k]);
@@ -949,15 +957,17 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
     }
 }
 
-template <int MT>   // 32-frame MFMA row tiles per workgroup
-__global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
+template <int MT, int NW>   // 32-frame MFMA row tiles per workgroup, waves per workgroup
+__global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
     const int n = lane & 31, kx = lane >> 5;
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
-    const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
+    PVQ_STAMP(0);
+    const int* my_list = a.list + wave * a.per_wave;
+    const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
     // MT == 2: a lane loads (Re, Im) of one of 64 frames; a half swap then leaves Re of frames 0..31 / Im of frames
     // 0..31 in the two lane halves of one register (the A operand of row tile 0) and frames 32..63 in the other.
     // MT == 1: a lane loads the one float it feeds to the MFMA.
@@ -984,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
     };
     BandBlock blk{};
     if (n_blocks > 0) {
-        blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave])];
+        blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[1])];
         open_block(blk);
     }
     for (int bi = 0; bi < n_blocks; ++bi) {
@@ -1029,13 +1039,20 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
         // the next block's first operands fly while this block's results are written out
         const int bin0 = blk.bin0, nrows = blk.nrows;
         if (bi + 1 < n_blocks) {
-            blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi + 1])];
+            blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
             open_block(blk);
         }
-        band_writeout<MT>(acc, dbs, a, f0, bin0, nrows, lane);
+        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, f0, bin0, nrows, lane);
     }
+    PVQ_STAMP(1);
     __syncthreads();
-    band_finish<MT>(dbs, a, f0, wave, lane);
+    PVQ_STAMP(2);
+    band_finish<MT, NW>(dbs, a, f0, wave, lane);
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        PVQ_STAMP(3);
+    }
 }
 
 // Split-bf16 form of the kernel product (the default, with the split-bf16 GEMM): the fp32 MFMA above runs at 1/16
@@ -1046,15 +1063,17 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db(BandArgs a) {
 // form — and splits them in registers; the coefficient planes come pre-split in B-operand order.
 constexpr int B3_NS = 3;   // 8-column stages in flight
 
-template <int MT>
-__global__ __launch_bounds__(256, 2) void blockdft_banddots_db_bf16x3(BandArgs a) {
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
     const int n = lane & 31, kx = lane >> 5;
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
-    const int n_blocks = wave == 0 ? a.cnt[0] : wave == 1 ? a.cnt[1] : wave == 2 ? a.cnt[2] : a.cnt[3];
+    PVQ_STAMP(0);
+    const int* my_list = a.list + wave * a.per_wave;
+    const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
     const float* xa = nullptr;
     const bf16x8* bp = nullptr;
     float2 av[B3_NS][MT][4];
@@ -1075,7 +1094,7 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db_bf16x3(BandArgs a
     };
     BandBlock blk{};
     if (n_blocks > 0) {
-        blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave])];
+        blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[1])];
         open_block(blk);
     }
     for (int bi = 0; bi < n_blocks; ++bi) {
@@ -1127,13 +1146,20 @@ __global__ __launch_bounds__(256, 2) void blockdft_banddots_db_bf16x3(BandArgs a
         // the next block's first operands fly while this block's results are written out
         const int bin0 = blk.bin0, nrows = blk.nrows;
         if (bi + 1 < n_blocks) {
-            blk = a.blocks[__builtin_amdgcn_readfirstlane(a.list[wave * a.per_wave + bi + 1])];
+            blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
             open_block(blk);
         }
-        band_writeout<MT>(acc, dbs, a, f0, bin0, nrows, lane);
+        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, f0, bin0, nrows, lane);
     }
+    PVQ_STAMP(1);
     __syncthreads();
-    band_finish<MT>(dbs, a, f0, wave, lane);
+    PVQ_STAMP(2);
+    band_finish<MT, NW>(dbs, a, f0, wave, lane);
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        PVQ_STAMP(3);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1355,15 +1381,24 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     band_B3.resize(band_B3.size() + (size_t)B3_NS * 3 * 64 * 8, 0);
     // blocks to waves: round robin in bin order, so that the four waves of a workgroup walk neighbouring blocks
     // (whose column ranges overlap) at the same time and share the X columns through L1 / L2
-    std::vector<std::vector<int>> per_wave(4);
-    for (size_t i = 0; i < band.size(); ++i) per_wave[i & 3].push_back((int)i);
-    t->band_per_wave = 1;
-    for (int w = 0; w < 4; ++w) t->band_per_wave = std::max(t->band_per_wave, (int)per_wave[w].size());
-    std::vector<int> band_list((size_t)4 * t->band_per_wave, 0);
-    for (int w = 0; w < 4; ++w) {
-        t->band_cnt[w] = (int)per_wave[w].size();
-        for (size_t i = 0; i < per_wave[w].size(); ++i) band_list[(size_t)w * t->band_per_wave + i] = per_wave[w][i];
-    }
+    // two sets of lists: for `band_waves` waves per workgroup (fp32 form) and for 4 (split-bf16 form, whose register
+    // budget does not fit four waves per SIMD)
+    t->band_waves = t->n_bins_pad <= 256 ? 8 : 4;   // the 64-frame form runs 8 waves per workgroup (4 waves per SIMD at 2 workgroups per CU)
+    t->band_per_wave = (int)band.size() + 2;
+    std::vector<int> band_list((size_t)(t->band_waves + 4) * t->band_per_wave, 0);
+    auto deal = [&](int first_row, int waves) {
+        // dealt round robin in bin order: the waves of a workgroup walk neighbouring blocks (overlapping column ranges)
+        // at the same time and share the X columns through L1 / L2 (balancing by cost instead was measured no faster)
+        std::vector<std::vector<int>> per_wave(waves);
+        for (size_t i = 0; i < band.size(); ++i) per_wave[i % waves].push_back((int)i);
+        for (int w = 0; w < waves; ++w) {
+            int* row = band_list.data() + (size_t)(first_row + w) * t->band_per_wave;
+            row[0] = (int)per_wave[w].size();
+            for (size_t i = 0; i < per_wave[w].size(); ++i) row[1 + i] = per_wave[w][i];
+        }
+    };
+    deal(0, t->band_waves);
+    deal(t->band_waves, 4);
     if (tile * CB_C >= 0x8000) {
         free_blockdft_tables(t);
         set_last_error("unsupported: too many spectrum columns for the block-DFT path");
@@ -1548,34 +1583,52 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.xcp = xcp;
         da.n_frames = (int)nf;
         da.n_bins = nb;
-        da.ldb = t->n_bins_pad + 4;   // 4 rows apart (the two lane halves of a C tile) land 16 banks apart
+        // 4 rows apart (the two lane halves of a C tile) land 16 banks apart; the 64-frame form has the stride compiled in
+        da.ldb = t->band_waves == 8 ? BAND_LDB2 : t->n_bins_pad + 4;
         da.blocks = t->d_band;
         da.B = t->d_band_B;
         da.B3 = t->d_band_B3;
         da.list = t->d_band_list;
         da.per_wave = t->band_per_wave;
-        for (int w = 0; w < 4; ++w) da.cnt[w] = t->band_cnt[w];
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
+        static const char* dstamps_env = getenv("PVQ_STAMPS_DOTS");   // developer knob: dump per-workgroup phase stamps once
+        static bool dstamps_done = false;
+        const bool do_dstamps = dstamps_env && !dstamps_done;
+        da.stamps = nullptr;
+        const size_t n_wg = (nf + 63) / 32;   // upper bound of the grid
+        if (do_dstamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&da.stamps), n_wg * 8 * 8));
+        if (do_dstamps) PVQ_HIP(hipMemset(da.stamps, 0, n_wg * 8 * 8));
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
-        static const int mt_env = getenv("PVQ_DOTS_MT") ? atoi(getenv("PVQ_DOTS_MT")) : 0;   // developer knob
-        const int mt = mt_env ? mt_env : (t->n_bins_pad <= 256 ? 2 : 1);
+        const int mt = t->band_waves == 8 ? 2 : 1;
         static const int dots_f32_env = getenv("PVQ_DOTS_F32") ? atoi(getenv("PVQ_DOTS_F32")) : 0;   // developer knob
         const bool dots_split = gemm_split_bf16_ && !dots_f32_env;   // the kernel product follows the GEMM arithmetic
         const size_t lds = sizeof(float) * 32 * mt * da.ldb;
         const dim3 grid((unsigned)((nf + 32 * mt - 1) / (32 * mt)));
         if (mt == 2) {
-            if (dots_split)
-                hipLaunchKernelGGL(blockdft_banddots_db_bf16x3<2>, grid, dim3(256), lds, stream, da);
-            else
-                hipLaunchKernelGGL(blockdft_banddots_db<2>, grid, dim3(256), lds, stream, da);
+            if (dots_split) {
+                da.list = t->d_band_list + (size_t)t->band_waves * t->band_per_wave;   // the 4-wave lists
+                hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<2, 4>), grid, dim3(256), lds, stream, da);
+            } else
+                hipLaunchKernelGGL((blockdft_banddots_db<2, 8>), grid, dim3(512), lds, stream, da);
         } else {
             if (dots_split)
-                hipLaunchKernelGGL(blockdft_banddots_db_bf16x3<1>, grid, dim3(256), lds, stream, da);
+                hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<1, 4>), grid, dim3(256), lds, stream, da);
             else
-                hipLaunchKernelGGL(blockdft_banddots_db<1>, grid, dim3(256), lds, stream, da);
+                hipLaunchKernelGGL((blockdft_banddots_db<1, 4>), grid, dim3(256), lds, stream, da);
         }
         slot_end(SLOT_BLOCKDFT_DOTS, stream);
+        if (do_dstamps) {
+            dstamps_done = true;
+            std::vector<unsigned long long> h(n_wg * 8);
+            PVQ_HIP(hipStreamSynchronize(stream));
+            PVQ_HIP(hipMemcpy(h.data(), da.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            PVQ_HIP(hipFree(da.stamps));
+            if (FILE* fp = fopen(dstamps_env, "wb")) {
+                fwrite(h.data(), 8, h.size(), fp);
+                fclose(fp);
+            }
+        }
     }
     if (pk) {
         slot_begin(SLOT_PEAKS, stream);
