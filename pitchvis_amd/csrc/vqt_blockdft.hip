@@ -70,6 +70,9 @@ struct BandBlock {
 constexpr int BD_RB = 16;   // bins per block: 32 MFMA columns = 16 x (re, im)
 constexpr int BD_KU = 4;    // columns per software-pipeline stage
 constexpr int BD_NS = 4;    // pipeline stages
+constexpr int BD8_RB = 8;   // bins per block of the 16x16x4 form
+constexpr int BD8_KU = 4;   // columns per stage (two column pairs = two MFMAs per 16-frame tile)
+constexpr int BD8_NS = 4;   // stages in the operand ring
 constexpr int X_PAD_COLS = 32;   // zeroed columns after the last X column (the operand prefetch runs past a block's range)
 
 struct BlockDftTables {
@@ -90,6 +93,11 @@ struct BlockDftTables {
     struct BandBlock* d_band = nullptr;
     float* d_band_B = nullptr;     // per block and column: 64 floats in v_mfma_f32_32x32x2_f32 B-operand lane order
     __bf16* d_band_B3 = nullptr;   // per block and 8 columns: 3 planes x 64 lanes x 8 bf16 in v_mfma_f32_32x32x16_bf16 order
+    // 8-bin blocks for the 16x16x4 MFMA form of the kernel product (fp32, 64-frame tiles)
+    struct BandBlock* d_band8 = nullptr;
+    float* d_band_B8 = nullptr;    // per block and column pair: 64 floats in v_mfma_f32_16x16x4_f32 B-operand lane order
+    int* d_band_list8 = nullptr;   // [8][band_per_wave8]
+    int band_per_wave8 = 0;
     int* d_band_list = nullptr;    // [band_waves][band_per_wave]: per wave of a workgroup, the count and then the blocks it walks
     int band_per_wave = 0;
     int band_waves = 4;            // waves per kernel-product workgroup (8 when the 64-frame form is used)
@@ -107,6 +115,9 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_comb_tw) (void)hipFree(t->d_comb_tw);
     if (t->d_band) (void)hipFree(t->d_band);
     if (t->d_band_B) (void)hipFree(t->d_band_B);
+    if (t->d_band8) (void)hipFree(t->d_band8);
+    if (t->d_band_B8) (void)hipFree(t->d_band_B8);
+    if (t->d_band_list8) (void)hipFree(t->d_band_list8);
     if (t->d_band_B3) (void)hipFree(t->d_band_B3);
     if (t->d_band_list) (void)hipFree(t->d_band_list);
     if (t->d_P) (void)hipFree(t->d_P);
@@ -1055,6 +1066,124 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
     }
 }
 
+// 16x16x4 form of the fp32 kernel product (64-frame tiles, up to 256 bins): blocks of 8 bins, so a block walks the union
+// of only 8 rows' columns (about 35 instead of 57) — the same products in 39 % fewer matrix-pipe cycles, which is what
+// bounds the 32x32x2 form's block phase.  A lane loads (Re, Im) of its frame for a pair of spectrum columns; two
+// v_permlane32_swap + two v_permlane16_swap transpose the four registers (Re c, Im c, Re c+1, Im c+1 over 64 frames) into
+// the A operands of the four 16-frame tiles (k = 0..3 in lane rows 0..3), one v_mfma_f32_16x16x4_f32 each; the B operand
+// of a column pair is one float per lane.  (Loading the A operands in lane order instead — four strided dword loads per
+// pair, no swaps — was measured slower: 185 vs 134 us; the stage is bound by vector-memory instructions, not by the
+// matrix pipe or by latency: ring depths 3 / 4 / 6 time the same.)  C layout: column n = lane & 15 (part = n >> 3, bin row = n & 7), frame =
+// 16 m + 4 (lane >> 4) + r; the im column's value reaches the re column's lane with a DPP row rotate.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int NW, int NS>
+__global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][BAND_LDB2]: |x_vqt|^2, then dB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = blockIdx.x * 64;
+    constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
+    const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride;
+    PVQ_STAMP(0);
+    const int* my_list = a.list + wave * a.per_wave;
+    const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
+    const float* xa = nullptr;
+    const float2* bp = nullptr;
+    float2 av[NS][BD8_KU];
+    float2 bv[NS];
+    static_assert(BD8_KU == 4, "a stage is two column pairs");
+    auto fetch = [&](int s, int c) {
+        bv[s] = bp[(size_t)(c / 4) * 64];
+#pragma unroll
+        for (int u = 0; u < BD8_KU; ++u) av[s][u] = *reinterpret_cast<const float2*>(xa + (size_t)(c + u) * col_stride);
+    };
+    auto open_block = [&](const BandBlock& blk) {
+        xa = xtile + (size_t)blk.x0 * col_stride + lane * 2;
+        bp = reinterpret_cast<const float2*>(a.B + (size_t)blk.boff * 64) + lane;
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) fetch(s, s * BD8_KU);
+    };
+    BandBlock blk{};
+    if (n_blocks > 0) {
+        blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[1])];
+        open_block(blk);
+    }
+    const int n = lane & 15, fr_lo = 4 * (lane >> 4);
+    for (int bi = 0; bi < n_blocks; ++bi) {
+        f32x4v acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][q] = 0.0f;
+        auto mul = [&](int s) {
+#pragma unroll
+            for (int u = 0; u < BD8_KU / 2; ++u) {
+                float r0 = av[s][2 * u].x, r1 = av[s][2 * u].y, r2 = av[s][2 * u + 1].x, r3 = av[s][2 * u + 1].y;
+                permlane32_swap(r0, r2);
+                permlane32_swap(r1, r3);
+                permlane16_swap(r0, r1);
+                permlane16_swap(r2, r3);
+                const float b = u ? bv[s].y : bv[s].x;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r0, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r1, b, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(r2, b, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(r3, b, acc[3], 0, 0, 0);
+            }
+        };
+        const int kb = __builtin_amdgcn_readfirstlane(blk.kb);
+        const int kb_full = kb - kb % (NS * BD8_KU);
+        int c = 0;
+        for (; c < kb_full; c += NS * BD8_KU) {   // steady state: no branches, exact load counting
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                fetch((s + NS - 1) % NS, c + (s + NS - 1) * BD8_KU);
+                mul(s);
+                __builtin_amdgcn_sched_barrier(0);   // keep a stage's lane swaps (and the waits on its operands) inside the stage
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)          // remainder: the operands are already in flight
+            if (c + s * BD8_KU < kb) mul(s);
+        const int bin0 = blk.bin0, nrows = blk.nrows;
+        if (bi + 1 < n_blocks) {                      // the next block's first operands fly during the write-out
+            blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
+            open_block(blk);
+        }
+        const bool mine = n < nrows;                  // re columns of live rows
+        const int bin = bin0 + n;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float im[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // row_ror:8: lane n <- lane n ^ 8 (through a scalar copy: the DPP of a vector element was seen merged across q)
+                const float re_q = acc[m][q];
+                im[q] = PVQ_DPP(re_q, 0x128);
+            }
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dbs[(16 * m + fr_lo + q) * BAND_LDB2 + bin] = acc[m][q] * acc[m][q] + im[q] * im[q];
+                if (a.out_cplx) {
+                    int row_stride = a.n_bins;
+                    asm volatile("" : "+s"(row_stride));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int fr = 16 * m + fr_lo + q;
+                        if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * row_stride + bin] = make_float2(acc[m][q], im[q]);
+                    }
+                }
+            }
+        }
+    }
+    PVQ_STAMP(1);
+    __syncthreads();
+    PVQ_STAMP(2);
+    band_finish<2, NW>(dbs, a, f0, wave, lane);
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        PVQ_STAMP(3);
+    }
+}
+
 // Split-bf16 form of the kernel product (the default, with the split-bf16 GEMM): the fp32 MFMA above runs at 1/16
 // of the bf16 matrix rate, and a 16-bin block is 73 % zeros, so the stage is matrix-bound.  Here X and the
 // coefficients are written as hi + mid + lo bf16 (exact 3-way split, see blockdft_gemm_tree_bf16x3) and eight
@@ -1354,6 +1483,89 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
             band.push_back(bb);
         }
     }
+    // The same coefficients for the 16x16x4 MFMA form: blocks of BD8_RB = 8 bins (16 output columns = 8 x (re, im)) walk the
+    // union of 8 rows' columns — about 35 instead of 57 columns per block, so 39 % fewer matrix operations for the same
+    // products.  B operand of a column pair, lane l (n = l & 15: part = n >> 3, row = n & 7; k = l >> 4: column k >> 1 of
+    // the pair, k & 1 = 0 multiplies Re X, 1 multiplies Im X).
+    std::vector<BandBlock> band8;
+    std::vector<float> band_B8;
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const CsrMatrix& A = groups[g].filter_bank;
+        const CsrMatrix& Bm = groups[g].negative_filter_bank;
+        const int xoff = t->groups[g].tile0 * CB_C;
+        for (uint32_t r0 = 0; r0 < A.rows; r0 += BD8_RB) {
+            const uint32_t r1 = std::min<uint32_t>(A.rows, r0 + BD8_RB);
+            int lo = 1 << 30, hi = -1;
+            for (uint32_t r = r0; r < r1; ++r) {
+                for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
+                    lo = std::min(lo, idx_of[g][A.col_idx[q]]);
+                    hi = std::max(hi, idx_of[g][A.col_idx[q]]);
+                }
+                if (Bm.nnz() > 0)
+                    for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
+                        lo = std::min(lo, idx_of[g][Bm.col_idx[q]]);
+                        hi = std::max(hi, idx_of[g][Bm.col_idx[q]]);
+                    }
+            }
+            if (hi < 0) {
+                lo = 0;
+                hi = 0;
+            }
+            BandBlock bb{};
+            bb.bin0 = (int)(groups[g].first_bin + r0);
+            bb.nrows = (int)(r1 - r0);
+            bb.boff = (int)(band_B8.size() / 64);   // in column pairs
+            bb.x0 = xoff + lo;
+            bb.kb = ((hi - lo + 1) + BD8_KU - 1) / BD8_KU * BD8_KU;
+            band_B8.resize(band_B8.size() + (size_t)(bb.kb / 2) * 64, 0.0f);
+            float* Bp = band_B8.data() + (size_t)bb.boff * 64;
+            // element (column cc, kk = Re / Im input, part = re / im output, row)
+            // pairs are stored two by two (one 8-byte load per lane and stage): pair p, lane l at ((p >> 1) * 64 + l) * 2 + (p & 1)
+            auto at8 = [&](int cc, int kk, int part, int row) -> float& {
+                const int pr = cc >> 1, l = ((cc & 1) * 2 + kk) * 16 + part * 8 + row;
+                return Bp[((size_t)(pr >> 1) * 64 + l) * 2 + (pr & 1)];
+            };
+            for (uint32_t r = r0; r < r1; ++r) {
+                const int row = (int)(r - r0);
+                for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
+                    const int ci = idx_of[g][A.col_idx[q]];
+                    const int cc = ci - lo;
+                    const double ar_ = A.values[q].re, ai_ = A.values[q].im;
+                    const float vr = (float)(ar_ * rho[g][ci].first - ai_ * rho[g][ci].second);
+                    const float vi = (float)(ar_ * rho[g][ci].second + ai_ * rho[g][ci].first);
+                    at8(cc, 0, 0, row) += vr;
+                    at8(cc, 1, 0, row) += -vi;
+                    at8(cc, 0, 1, row) += vi;
+                    at8(cc, 1, 1, row) += vr;
+                }
+                if (Bm.nnz() > 0)
+                    for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
+                        const int ci = idx_of[g][Bm.col_idx[q]];
+                        const int cc = ci - lo;
+                        const double br_ = Bm.values[q].re, bi_ = Bm.values[q].im;
+                        const float wr = (float)(br_ * rho[g][ci].first - bi_ * rho[g][ci].second);
+                        const float wi = (float)(br_ * rho[g][ci].second + bi_ * rho[g][ci].first);
+                        at8(cc, 0, 0, row) += wr;
+                        at8(cc, 1, 0, row) += -wi;
+                        at8(cc, 0, 1, row) += -wi;
+                        at8(cc, 1, 1, row) += -wr;
+                    }
+            }
+            band8.push_back(bb);
+        }
+    }
+    band_B8.resize(band_B8.size() + (size_t)8 * (BD8_KU / 2) * 64, 0.0f);   // the prefetch of the last block runs on past it
+    t->band_per_wave8 = (int)band8.size() + 2;
+    std::vector<int> band_list8((size_t)8 * t->band_per_wave8, 0);
+    {
+        std::vector<std::vector<int>> per_wave(8);
+        for (size_t i = 0; i < band8.size(); ++i) per_wave[i % 8].push_back((int)i);
+        for (int w = 0; w < 8; ++w) {
+            int* row = band_list8.data() + (size_t)w * t->band_per_wave8;
+            row[0] = (int)per_wave[w].size();
+            for (size_t i = 0; i < per_wave[w].size(); ++i) row[1 + i] = per_wave[w][i];
+        }
+    }
     band_B.resize(band_B.size() + (size_t)BD_NS * BD_KU * 64, 0.0f);   // the prefetch of the last block runs on past it
     // split-bf16 planes of the same coefficients, 8 columns (16 real k) per MFMA: lane (n = l & 31, kh = l >> 5)
     // holds k = 8 kh + t, t = 0..7  <->  column 4 kh + t / 2, Re / Im row t & 1
@@ -1409,7 +1621,8 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
     t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
-              up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) &&
+              up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
+              up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3);
     if (!ok) {
         free_blockdft_tables(t);
@@ -1601,6 +1814,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         if (do_dstamps) PVQ_HIP(hipMemset(da.stamps, 0, n_wg * 8 * 8));
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
         const int mt = t->band_waves == 8 ? 2 : 1;
+        static const int dots16_env = getenv("PVQ_DOTS_16BIN") ? atoi(getenv("PVQ_DOTS_16BIN")) : 0;   // developer knob: the 32x32x2 form
         static const int dots_f32_env = getenv("PVQ_DOTS_F32") ? atoi(getenv("PVQ_DOTS_F32")) : 0;   // developer knob
         const bool dots_split = gemm_split_bf16_ && !dots_f32_env;   // the kernel product follows the GEMM arithmetic
         const size_t lds = sizeof(float) * 32 * mt * da.ldb;
@@ -1609,8 +1823,21 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             if (dots_split) {
                 da.list = t->d_band_list + (size_t)t->band_waves * t->band_per_wave;   // the 4-wave lists
                 hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<2, 4>), grid, dim3(256), lds, stream, da);
-            } else
+            } else if (dots16_env) {
                 hipLaunchKernelGGL((blockdft_banddots_db<2, 8>), grid, dim3(512), lds, stream, da);
+            } else {   // 8-bin blocks, 16x16x4 MFMAs
+                da.blocks = t->d_band8;
+                da.B = t->d_band_B8;
+                da.list = t->d_band_list8;
+                da.per_wave = t->band_per_wave8;
+                static const int ns_env = getenv("PVQ_DOTS_NS") ? atoi(getenv("PVQ_DOTS_NS")) : 0;   // developer knob: operand ring depth
+                if (ns_env == 3)
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 3>), grid, dim3(512), lds, stream, da);
+                else if (ns_env == 6)
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 6>), grid, dim3(512), lds, stream, da);
+                else
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS>), grid, dim3(512), lds, stream, da);
+            }
         } else {
             if (dots_split)
                 hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<1, 4>), grid, dim3(256), lds, stream, da);
