@@ -149,106 +149,6 @@ struct GemmArgs {
     int p_rows;               // row capacity of the tile-major P: P[(tile64 * p_rows + row) * 64 + (col & 63)]
 };
 
-// BM x BN output tile, BK k-step, WM x WN waves, each wave (BM/WM) x (BN/WN) as TM x TN 32x32 MFMA tiles.
-// A (the PCM stream seen as [block][hop]) is fetched with raw buffer loads: samples before the
-// stream start or past its end come back as 0 from the hardware range check, no per-element compares.
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void blockdft_gemm(GemmArgs a) {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_PER = BM * BK / NT;            // dwords of A per thread per k-step
-    constexpr int A_ROWS_PER_PASS = NT / BK;
-    constexpr int BV = (BK * BN / NT >= 4) ? 4 : (BK * BN / NT);   // floats per B vector load (4, 2 or 1)
-    constexpr int B_PER = BK * BN / BV / NT;       // vector loads of B per thread per k-step
-    constexpr int B_ROWS_PER_PASS = NT * BV / BN;
-    static_assert(A_PER >= 1 && B_PER >= 1 && BV >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
-    typedef float bvec_t __attribute__((ext_vector_type(BV)));
-    __shared__ float As[2][BM][BK + 1];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
-    // so give every XCD whole row panels: all column tiles that re-read one A panel hit one L2.
-    const int b = blockIdx.x;
-    const int xcd = b & 7, bi = b >> 3;
-    const int nt = bi % a.n_col_tiles;
-    const int mt = (bi / a.n_col_tiles) * 8 + xcd;
-    if (mt * BM >= a.n_rows) return;
-    const int j0 = mt * BM;
-    const int wm = wave / WN, wn = wave % WN;
-    // every 64-float tile inside this BN-wide tile belongs to the same group (groups are padded to BN)
-    const long long s = a.base + a.tile_s[nt * (BN / 64)];
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
-
-    float ra[A_PER];
-    bvec_t rb[B_PER];
-    const int a_row = tid / BK, a_col = tid % BK;
-    const int b_row = (tid * BV) / BN, b_col = (tid * BV) % BN;
-    // byte offset of A[j0 + a_row][a_col]; negative indices wrap to huge unsigned offsets -> out of range -> 0
-    const unsigned a_off0 = (unsigned)((s + (long long)(j0 + a_row) * a.K + a_col) * 4ll);
-    const unsigned a_pass = (unsigned)(A_ROWS_PER_PASS * a.K * 4);
-    const float* e_ptr = a.E + (size_t)b_row * a.ld + (size_t)nt * BN + b_col;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-#define PVQ_GEMM_LOAD(k0)                                                                                      \
-    {                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) ra[i] = __builtin_bit_cast(                          \
-            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, a_off0 + (unsigned)i * a_pass + (unsigned)(k0)*4u, 0, 0)); \
-        _Pragma("unroll") for (int i = 0; i < B_PER; ++i) rb[i] =                                              \
-            *reinterpret_cast<const bvec_t*>(e_ptr + (size_t)((k0) + i * B_ROWS_PER_PASS) * a.ld);             \
-    }
-#define PVQ_GEMM_STORE(buf)                                                                                    \
-    {                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) As[buf][a_row + i * A_ROWS_PER_PASS][a_col] = ra[i]; \
-        _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                                      \
-            *reinterpret_cast<bvec_t*>(&Bs[buf][b_row + i * B_ROWS_PER_PASS][b_col]) = rb[i];                  \
-    }
-
-    const int n_iter = a.K / BK;
-    PVQ_GEMM_LOAD(0);
-    PVQ_GEMM_STORE(0);
-    __syncthreads();
-    const int ar = wm * (BM / WM) + (lane & 31), kh = lane >> 5, bc = wn * (BN / WN) + (lane & 31);
-    for (int it = 0; it < n_iter; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < n_iter) PVQ_GEMM_LOAD((it + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[buf][ar + 32 * i][2 * kk + kh];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][2 * kk + kh][bc + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (it + 1 < n_iter) PVQ_GEMM_STORE(buf ^ 1);
-        __syncthreads();
-    }
-#undef PVQ_GEMM_LOAD
-#undef PVQ_GEMM_STORE
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = nt * BN + wn * (BN / WN) + 32 * j + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = j0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a.n_rows) a.P[((size_t)(col >> 6) * a.p_rows + row) * 64 + (col & 63)] = acc[i][j][r];
-            }
-        }
-}
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------------
@@ -476,8 +376,8 @@ __device__ __forceinline__ void fused_f32_stage_load(const i32x4& rsrc4, __amdgp
     }
 }
 
-template <bool VEC, int BM>
-__device__ __forceinline__ void fused_f32_kloop(const GemmTreeArgs& a, float* smem, long long idx_f0, long long idx_b0, const float* e_tile,
+template <bool VEC, int BM, typename Args>
+__device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long long idx_f0, long long idx_b0, const float* e_tile,
                                                 int tid, f32x16& acc0, f32x16& acc1) {
     constexpr int THREADS = 2 * BM;
     const int lane = tid & 63;
@@ -558,6 +458,46 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
     __syncthreads();
     PVQ_STAMP(5);
     fused_tree_store<BM>(smem, tw_lds, T, a, tid);
+}
+
+// Unfused form of the same GEMM (windows of more than 64 hop blocks: the tree runs as its own kernel over P' in memory):
+// BM rows x 32 complex columns per workgroup, the K loop of the fused kernel, P' written tile-major as (re, im) pairs.
+template <int BM>
+__global__ __launch_bounds__(2 * BM, 2) void blockdft_gemm_rows(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[FR_KC * FT_BN];   // the E slice
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: workgroups are dealt round robin over the 8 XCDs (b and b + 8 share an L2), so an XCD owns
+    // whole row panels: all column tiles that re-read one panel of the stream hit one L2
+    const int b = blockIdx.x;
+    const int xcd = b & 7, bi = b >> 3;
+    const int nt = bi % a.n_col_tiles;
+    const int mt = (bi / a.n_col_tiles) * 8 + xcd;
+    if (mt * BM >= a.n_rows) return;
+    const int j0 = mt * BM;
+    const long long s = a.base + a.tile_s[nt];
+    const long long tile_lo = s + (long long)j0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;
+    const long long row0 = tile_lo + (long long)(wave * 32 + (lane & 31)) * a.K;
+    const int half = lane >> 5;
+    const long long off_f0 = row0 + 16 * half;
+    const long long off_b0 = row0 + a.K - 16 - 16 * half;
+    const float* e_tile = a.E + (size_t)nt * FT_BN;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc0[q] = 0.0f;
+        acc1[q] = 0.0f;
+    }
+    if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
+        fused_f32_kloop<true, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+    else
+        fused_f32_kloop<false, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5); a row of the tile is 256 contiguous bytes
+    float2* Pt = reinterpret_cast<float2*>(a.P) + (size_t)nt * a.p_rows * CB_C;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = j0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < a.n_rows) Pt[(size_t)row * CB_C + (lane & 31)] = make_float2(acc0[q], acc1[q]);
+    }
 }
 
 // Split-bf16 form of the fused kernel ("bf16x3", the default; pvq_vqt_set_gemm_precision): same tile, same
@@ -1311,7 +1251,7 @@ static inline float host_from_bf16(uint16_t h) {
 uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_t)(dev_->block->n_tiles * CB_C) : 0u; }
 
 bool Vqt::blockdft_applicable(size_t hop) const {
-    if (!has_device() || hop < 32 || (hop & (hop - 1)) != 0 || hop > 4096) return false;
+    if (!has_device() || hop < 64 || (hop & (hop - 1)) != 0 || hop > 4096) return false;   // the mirrored K loop walks hop / 2 in stages of 32
     if (n_bins() > 1024) return false;
     for (const WindowGroup& g : plan_.kernel.window_groups) {
         const size_t ws = g.window_size();
@@ -1768,9 +1708,9 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             ga.base = base;
             ga.n_col_tiles = t->n_tiles;
             ga.p_rows = (int)rows_cap;
-            const int m_tiles8 = (((n_rows + 127) / 128) + 7) / 8 * 8;
+            const int m_tiles8 = (((n_rows + 255) / 256) + 7) / 8 * 8;
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-            hipLaunchKernelGGL((blockdft_gemm<128, 64, 16, 2, 2>), dim3(ga.n_col_tiles * m_tiles8), dim3(256), 0, stream, ga);
+            hipLaunchKernelGGL(blockdft_gemm_rows<256>, dim3(ga.n_col_tiles * m_tiles8), dim3(512), 0, stream, ga);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
             CombineArgs ca;
             ca.P = t->d_P;
