@@ -55,6 +55,8 @@ struct BlockGroup {
     int n_tiles;    // column tiles (of 32 complex columns)
     int tw_off;     // into d_comb_tw: levels x (n_tiles*32) entries
     long long s_rel;  // window begin relative to the end of the n_fft buffer: w0 - n_fft
+    int nb_f;       // blocks summed inside the fused kernel: min(nb, 64); the remaining levels run in blockdft_tree_finish
+    int levels_f;   // log2(nb_f)
 };
 
 // 16 output bins (rows of one window group's kernel) and the contiguous range of X columns they read
@@ -103,6 +105,7 @@ struct BlockDftTables {
     int band_waves = 4;            // waves per kernel-product workgroup (8 when the 64-frame form is used)
     float* d_P = nullptr;  size_t p_cap = 0;   // workspace
     float2* d_X = nullptr; size_t x_cap = 0;
+    float2* d_Y = nullptr; size_t y_cap = 0;   // 64-block partial sums (windows of more than 64 blocks)
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -122,6 +125,7 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_band_list) (void)hipFree(t->d_band_list);
     if (t->d_P) (void)hipFree(t->d_P);
     if (t->d_X) (void)hipFree(t->d_X);
+    if (t->d_Y) (void)hipFree(t->d_Y);
     delete t;
 }
 
@@ -165,6 +169,7 @@ struct GemmTreeArgs {
     const float* E;           // [K][Ntot], (cos, sin) of e^{-i th_c u_m} interleaved per column; the fp32 form reads rows m < K/2
     int ld;                   // Ntot
     float2* X;                // frame-tile blocked: X[((frame / 64) * xcp + col) * 64 + frame % 64]
+    float2* Y;                // same layout, 64-block partial sums of the groups whose windows span more than 64 blocks
     int xcp;                  // columns per frame tile (incl. the zeroed pad columns)
     int n_frames;             // frames of this launch
     int K;                    // hop
@@ -187,6 +192,7 @@ struct FusedTile {
     int S;        // complete frames per row tile
     int ntl, nt;  // column tile within the group / global
     int f0;       // first frame == first block row
+    int nfr;      // rows this group produces: n_frames complete frames, or n_frames + nb - 64 partial sums when nb > 64
 };
 template <int BM = FT_BM>
 __device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
@@ -194,7 +200,8 @@ __device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
     int g = 0;
     while (g + 1 < a.n_groups && (int)blockIdx.x >= a.blk_off[g + 1]) ++g;
     t.G = a.groups[g];
-    t.S = BM - t.G.nb + 1;
+    t.S = BM - t.G.nb_f + 1;
+    t.nfr = a.n_frames + t.G.nb - t.G.nb_f;
     const int r = blockIdx.x - a.blk_off[g];
     const int xcd = r & 7, bi = r >> 3;                 // XCD-aware: an XCD owns whole row panels
     t.ntl = bi % t.G.n_tiles;
@@ -210,7 +217,7 @@ constexpr int FT_LDP = CB_C + 1;                      // P tile row stride in co
 constexpr int FT_MAXL = 6;
 __device__ __forceinline__ void fused_stage_twiddles(float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid) {
     const int l = tid >> 5, c = tid & (CB_C - 1);
-    if (l < t.G.levels) tw[l][c] = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
+    if (l < t.G.levels_f) tw[l][c] = a.comb_tw[t.G.tw_off + l * (t.G.n_tiles * CB_C) + t.ntl * CB_C + c];
 }
 
 // lo + w * hi with a fixed operation order — (re, im) = fma((-w.y, w.y), (hi.y, hi.x), fma((w.x, w.x), (hi.x, hi.y), lo)),
@@ -257,7 +264,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     constexpr int THREADS = 2 * BM;
     constexpr int PER = BM * CB_C / THREADS;  // 16
     auto cmadd = [](float2 lo, float2 w, float2 hi) { return tree_cmadd(lo, w, hi); };
-    const int levels = t.G.levels;
+    const int levels = t.G.levels_f;
     int l = levels < 4 ? levels : 4;
     switch (l) {   // wave-uniform
         case 1: fused_tree_register_levels<1, BM>(A, tw, tid); break;
@@ -318,8 +325,9 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     // lanes walk the frames of one column: 512-byte runs in memory, conflict-free LDS reads
     const int j = tid & (BM - 1);
     const int f = t.f0 + j;
-    if (j < t.S && f < a.n_frames) {
-        float2* dst = a.X + ((size_t)(f >> 6) * a.xcp + t.nt * CB_C) * 64 + (f & 63);
+    if (j < t.S && f < t.nfr) {
+        // windows of more than 64 blocks: 64-block partial sums go to Y, blockdft_tree_finish adds the last levels
+        float2* dst = (t.G.nb > t.G.nb_f ? a.Y : a.X) + ((size_t)(f >> 6) * a.xcp + t.nt * CB_C) * 64 + (f & 63);
 #pragma unroll 4
         for (int cc = tid / BM; cc < CB_C; cc += 2) dst[cc * 64] = A[j][cc];
     }
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FusedTile T = fused_tile<BM>(a);
     const int f0 = T.f0, nt = T.nt;
-    if (f0 >= a.n_frames) return;
+    if (f0 >= T.nfr) return;
     PVQ_STAMP(0);
     if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
     const long long s = a.base + T.G.s_rel;
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FusedTile T = fused_tile<BM>(a);
     const int f0 = T.f0, nt = T.nt;
-    if (f0 >= a.n_frames) return;
+    if (f0 >= T.nfr) return;
     if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
     const int wm = wave >> 1, wn = wave & 1;
     const long long s = a.base + T.G.s_rel;
@@ -655,6 +663,41 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
     }
     __syncthreads();
     fused_tree_store<BM>(smem, tw_lds, T, a, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Last tree levels for windows of more than 64 hop blocks: the fused kernel leaves Y_f = sum_{b<64} phi^b P'[f+b];
+// X'_f = sum_q phi^{64 q} Y_{f+64q} (2 or 4 terms) with the same level-by-level multiply-adds as the rest of the tree.
+// Y_{f+64q} is the same lane of the same column q frame tiles further on: 512-byte runs in, 512-byte runs out.
+// ------------------------------------------------------------------------------------------------
+struct FinishArgs {
+    const float2* Y;
+    float2* X;
+    int xcp;
+    int n_frames;
+    int col0;          // first X column of the group
+    int n_cols;        // columns of the group (padded to its tiles)
+    int levels_f, levels;
+    const float2* tw;  // the group's combine twiddles: [levels][n_cols]
+};
+__global__ __launch_bounds__(256) void blockdft_tree_finish(FinishArgs a) {
+    const int fr = threadIdx.x & 63, cc = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tile = blockIdx.x;
+    if (cc >= a.n_cols || tile * 64 + fr >= a.n_frames) return;
+    const int col = a.col0 + cc;
+    const int nq = 1 << (a.levels - a.levels_f);   // 2 or 4
+    float2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (q < nq) v[q] = a.Y[((size_t)(tile + q) * a.xcp + col) * 64 + fr];
+    const float2 w0 = a.tw[(size_t)a.levels_f * a.n_cols + cc];
+    if (nq == 2) {
+        v[0] = tree_cmadd(v[0], w0, v[1]);
+    } else {
+        const float2 w1 = a.tw[(size_t)(a.levels_f + 1) * a.n_cols + cc];
+        v[0] = tree_cmadd(tree_cmadd(v[0], w0, v[1]), w1, tree_cmadd(v[2], w0, v[3]));
+    }
+    a.X[((size_t)tile * a.xcp + col) * 64 + fr] = v[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1300,6 +1343,8 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         B.nb = (int)(groups[g].window_size() / hop);
         B.levels = 0;
         while ((1 << B.levels) < B.nb) ++B.levels;
+        B.nb_f = std::min(B.nb, 64);
+        B.levels_f = std::min(B.levels, 6);
         B.n_cols = (int)col_of[g].size();
         B.tile0 = tile;
         B.n_tiles = (B.n_cols + CB_C - 1) / CB_C;
@@ -1597,7 +1642,16 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     }
     const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
     static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
-    const bool fused = fuse_env && t->nb_max <= 64 && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
+    const bool fused = fuse_env && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
+    if (fused && t->nb_max > 64) {
+        const size_t y_bytes = (chunk + (size_t)(t->nb_max - 64) + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
+        if (t->y_cap < y_bytes) {
+            if (t->d_Y) PVQ_HIP(hipFree(t->d_Y));
+            t->d_Y = nullptr; t->y_cap = 0;
+            PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_Y), y_bytes));
+            t->y_cap = y_bytes;
+        }
+    }
     if (!fused) {
         const size_t p_bytes = rows_cap * ntot * sizeof(float);
         if (t->p_cap < p_bytes) {
@@ -1646,6 +1700,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.E = t->d_E;
             fa.ld = ntot;
             fa.X = X;
+            fa.Y = t->d_Y;
             fa.xcp = xcp;
             fa.n_frames = (int)nf;
             fa.K = (int)hop;
@@ -1659,8 +1714,9 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             int off = 0;
             for (int g = 0; g < t->n_groups; ++g) {
                 fa.blk_off[g] = off;
-                const int S = fused_bm - t->groups[g].nb + 1;
-                const int mt8 = ((((int)nf + S - 1) / S) + 7) / 8 * 8;
+                const int S = fused_bm - t->groups[g].nb_f + 1;
+                const int rows_g = (int)nf + t->groups[g].nb - t->groups[g].nb_f;
+                const int mt8 = (((rows_g + S - 1) / S) + 7) / 8 * 8;
                 off += t->groups[g].n_tiles * mt8;
             }
             for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
@@ -1693,6 +1749,26 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     fwrite(h.data(), 8, h.size(), fp);
                     fclose(fp);
                 }
+            }
+            if (t->nb_max > 64) {   // the last one or two tree levels of the long windows
+                slot_begin(SLOT_BLOCKDFT_COMBINE, stream);
+                for (int g = 0; g < t->n_groups; ++g) {
+                    const BlockGroup& G = t->groups[g];
+                    if (G.nb <= G.nb_f) continue;
+                    FinishArgs fin;
+                    fin.Y = t->d_Y;
+                    fin.X = X;
+                    fin.xcp = xcp;
+                    fin.n_frames = (int)nf;
+                    fin.col0 = G.tile0 * CB_C;
+                    fin.n_cols = G.n_tiles * CB_C;
+                    fin.levels_f = G.levels_f;
+                    fin.levels = G.levels;
+                    fin.tw = t->d_comb_tw + G.tw_off;
+                    hipLaunchKernelGGL(blockdft_tree_finish, dim3((unsigned)((nf + 63) / 64), (unsigned)((fin.n_cols + 3) / 4)), dim3(256), 0,
+                                       stream, fin);
+                }
+                slot_end(SLOT_BLOCKDFT_COMBINE, stream);
             }
         } else {
             const int n_rows = (int)(nf + t->nb_max - 1);

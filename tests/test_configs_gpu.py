@@ -170,3 +170,39 @@ def test_two_handles_two_streams():
     torch.cuda.synchronize()
     for x, y in zip(ra + rb, qa + qb):
         assert torch.equal(x, y)
+
+
+def test_unfused_fallback_stages_in_a_subprocess():
+    """The unfused GEMM + combine stages (taken when a geometry has more than 8 window groups; developer knob
+    PVQ_NO_FUSE=1) against the FFT path, in a child process because the knob is read once per process."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, os
+        sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+        import numpy as np, torch
+        import pitchvis_amd as P
+        from helpers import get_geom, white_noise
+        for name, hop in (("bench_48k_252", 256), ("hires_96k_360", 128)):
+            pp, op = get_geom(name)
+            v = P.Vqt.new(pp, 0)
+            nf, n_lead = 200, 70000   # full windows from the first frame on (n_fft <= 65536)
+            pcm = torch.from_numpy(white_noise(n_lead + hop * nf, 5)).cuda()
+            out = {}
+            for algo in (P.ALGO_BLOCKDFT, P.ALGO_FFT):
+                v.set_algo(algo)
+                cx = torch.zeros((nf, v.n_bins, 2), device="cuda")
+                db = torch.empty((nf, v.n_bins), device="cuda")
+                v.calculate_batch_db_device(pcm, hop, nf, db, n_lead=n_lead, d_out_cplx=cx)
+                torch.cuda.synchronize()
+                assert v.last_algo() == algo
+                out[algo] = cx.cpu().numpy().view(np.complex64)[..., 0]
+                launches = v.last_kernel_launches() if hasattr(v, "last_kernel_launches") else {}
+            a, b = out[P.ALGO_BLOCKDFT], out[P.ALGO_FFT]
+            err = (np.abs(a - b) / np.abs(b).max(axis=1, keepdims=True)).max()
+            assert err <= 1e-5, (name, err)
+        print("UNFUSED_OK")
+    """)
+    env = dict(os.environ, PVQ_NO_FUSE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "UNFUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
