@@ -205,50 +205,51 @@ __device__ inline void pk_distance_filter(const float* x, int n, const uint8_t* 
 // becomes kept (none of them kept) or removed (one of them kept).  Each round settles at least the highest
 // undecided candidate of every neighbourhood; a noisy frame needs a handful of rounds.
 // keep[i]: 0 = no candidate / removed, 1 = kept, 2 = undecided (on return only 0 / 1).
-// tmp: npad bytes of scratch (the states ping-pong between keep and tmp, a round reads one and writes the other)
+// The candidates (about a third of the bins) are compacted into `list` first, so a round costs ceil(candidates / 64)
+// steps instead of ceil(bins / 64).  States are updated in place: they only ever go 2 -> 0 or 2 -> 1, "removed" needs a
+// kept higher-priority neighbour and "kept" needs all of them removed — both verdicts stay true whatever happens later, so
+// it does not matter whether a lane sees a neighbour's state from before or after this step.
+// list: room for n / 2 + 1 u16 (strict local maxima and plateau tops are never adjacent).
 __device__ __forceinline__ void pk_distance_wave(const float* x, int n, const uint8_t* cand, float min_height, int dist, uint8_t* keep,
-                                                 uint8_t* tmp, int lane) {
-    for (int i = lane; i < n; i += 64) keep[i] = (cand[i] && x[i] >= min_height) ? 2 : 0;
+                                                 uint16_t* list, int lane) {
+    int n_list = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool c = i < n && cand[i] && x[i] >= min_height;
+        if (i < n) keep[i] = c ? 2 : 0;
+        const unsigned long long bm = __ballot(c);
+        if (c) list[n_list + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        n_list += __popcll(bm);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint8_t* cur = keep;
-    uint8_t* nxt = tmp;
     for (int round = 0; round < n; ++round) {   // terminates long before: every round decides at least one candidate
         bool any = false;
-        for (int i = lane; i < n; i += 64) {
-            uint8_t st = cur[i];
-            if (st == 2) {
-                const float h = x[i];
-                bool blocked = false, killed = false;
-                for (int d = 1; d < dist; ++d) {
+        for (int k = lane; k < n_list; k += 64) {
+            const int i = list[k];
+            if (keep[i] != 2) continue;
+            const float h = x[i];
+            bool blocked = false, killed = false;
+            for (int d = 1; d < dist; ++d) {
 #pragma unroll
-                    for (int sgn = -1; sgn <= 1; sgn += 2) {
-                        const int j = i + sgn * d;
-                        if (j < 0 || j >= n) continue;
-                        const uint8_t sj = cur[j];
-                        if (sj == 0) continue;
-                        const float hj = x[j];
-                        if (!(hj > h || (hj == h && j > i))) continue;   // lower priority: cannot remove this one
-                        if (sj == 1) killed = true;
-                        else blocked = true;
-                    }
+                for (int sgn = -1; sgn <= 1; sgn += 2) {
+                    const int j = i + sgn * d;
+                    if (j < 0 || j >= n) continue;
+                    const uint8_t sj = keep[j];
+                    if (sj == 0) continue;
+                    const float hj = x[j];
+                    if (!(hj > h || (hj == h && j > i))) continue;   // lower priority: cannot remove this one
+                    if (sj == 1) killed = true;
+                    else blocked = true;
                 }
-                st = killed ? 0 : (blocked ? 2 : 1);
-                any |= st == 2;
             }
-            nxt[i] = st;
+            if (killed) keep[i] = 0;
+            else if (!blocked) keep[i] = 1;
+            else any = true;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint8_t* t = cur;
-        cur = nxt;
-        nxt = t;
         if (!__ballot(any)) break;
-    }
-    if (cur != keep) {
-        for (int i = lane; i < n; i += 64) keep[i] = cur[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -287,9 +288,9 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.dist > 1) {
-        uint8_t* tmp = keep1 + npad;   // the area the serial filter used for its sort lists
-        pk_distance_wave(x, n, cand, a.bass_min_height, a.dist, keep0, tmp, lane);
-        pk_distance_wave(x, n, cand, a.peak_min_height, a.dist, keep1, tmp, lane);
+        uint16_t* dl = reinterpret_cast<uint16_t*>(keep1 + npad);   // the area the serial filter used for its sort lists
+        pk_distance_wave(x, n, cand, a.bass_min_height, a.dist, keep0, dl, lane);
+        pk_distance_wave(x, n, cand, a.peak_min_height, a.dist, keep1, dl, lane);
     }
     float v[NK];
 #pragma unroll
@@ -412,9 +413,8 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     }
     if (__ballot(plateau)) return false;
     if (DISTANCE) {   // find_peaks' distance rule runs before its prominence test, once per height threshold
-        pk_distance_wave(x, n, lmax, a.bass_min_height, a.dist, keep0, flag, lane);
-        pk_distance_wave(x, n, lmax, a.peak_min_height, a.dist, keep1, flag, lane);
-        for (int i = lane; i < npad; i += 64) flag[i] = 0;   // it served as the ping-pong buffer
+        pk_distance_wave(x, n, lmax, a.bass_min_height, a.dist, keep0, clist, lane);   // clist is free until step 1
+        pk_distance_wave(x, n, lmax, a.peak_min_height, a.dist, keep1, clist, lane);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
