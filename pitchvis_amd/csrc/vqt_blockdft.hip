@@ -838,6 +838,7 @@ __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 // offset; the optional complex output recomputes its addresses per block (the row stride is laundered through an
 // asm so that 32 loop-invariant 64-bit addresses are not kept live across the whole block loop).
 constexpr int BAND_LDB2 = 260;   // the 64-frame form: up to 256 bins + 4 (rows 4 apart land 16 banks apart)
+constexpr int BAND_LDB3 = 308;   // the 64-frame 8-bin form up to 304 bins (78.8 KB: still two workgroups per CU)
 template <int MT, int LDB>
 __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, int f0, int bin0, int nrows,
                                               int lane) {
@@ -877,9 +878,9 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 // power_to_db per frame (vqt.rs:922-954): a wave per frame, lanes over bins.  Up to 512 bins: four (two) frames at a
 // time with their dB values in registers, so the read -> log -> reduce -> rescale chains of the frames overlap
 // (the phase is latency-bound at two waves per SIMD); more bins: one frame at a time through LDS.
-template <int MT, int NW>
+template <int MT, int NW, int LDB = (MT == 2 ? BAND_LDB2 : 0)>
 __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f0, int wave, int lane) {
-    const int ldb = MT == 2 ? BAND_LDB2 : a.ldb;
+    const int ldb = LDB ? LDB : a.ldb;
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
     auto to_db = [&](float p) { return 3.01029995663981f * __log2f(fmaxf(p, PVQ_A_MIN)) - ref_db; };
@@ -1059,9 +1060,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
 // matrix pipe or by latency: ring depths 3 / 4 / 6 time the same.)  C layout: column n = lane & 15 (part = n >> 3, bin row = n & 7), frame =
 // 16 m + 4 (lane >> 4) + r; the im column's value reaches the re column's lane with a DPP row rotate.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int NW, int NS>
+template <int NW, int NS, int LDB>   // LDB: row stride of the LDS tile (4 mod 16, >= bins)
 __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][BAND_LDB2]: |x_vqt|^2, then dB
+    extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][LDB]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * 64;
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArg
             }
             if (mine) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dbs[(16 * m + fr_lo + q) * BAND_LDB2 + bin] = acc[m][q] * acc[m][q] + im[q] * im[q];
+                for (int q = 0; q < 4; ++q) dbs[(16 * m + fr_lo + q) * LDB + bin] = acc[m][q] * acc[m][q] + im[q] * im[q];
                 if (a.out_cplx) {
                     int row_stride = a.n_bins;
                     asm volatile("" : "+s"(row_stride));
@@ -1159,7 +1160,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArg
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<2, NW>(dbs, a, f0, wave, lane);
+    band_finish<2, NW, LDB>(dbs, a, f0, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1580,7 +1581,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     // (whose column ranges overlap) at the same time and share the X columns through L1 / L2
     // two sets of lists: for `band_waves` waves per workgroup (fp32 form) and for 4 (split-bf16 form, whose register
     // budget does not fit four waves per SIMD)
-    t->band_waves = t->n_bins_pad <= 256 ? 8 : 4;   // the 64-frame form runs 8 waves per workgroup (4 waves per SIMD at 2 workgroups per CU)
+    t->band_waves = 8;   // fp32 forms: 8 waves per workgroup (4 waves per SIMD when two workgroups fit a CU)
     t->band_per_wave = (int)band.size() + 2;
     std::vector<int> band_list((size_t)(t->band_waves + 4) * t->band_per_wave, 0);
     auto deal = [&](int first_row, int waves) {
@@ -1813,7 +1814,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.n_frames = (int)nf;
         da.n_bins = nb;
         // 4 rows apart (the two lane halves of a C tile) land 16 banks apart; the 64-frame form has the stride compiled in
-        da.ldb = t->band_waves == 8 ? BAND_LDB2 : t->n_bins_pad + 4;
+        // more than 256 bins (32-frame tiles): the smallest stride >= n_bins that is 4 mod 16, so that up to 596 bins still fit two workgroups per CU
+        // 64-frame tiles while two 64-row tiles fit a CU: up to 256 bins (stride 260) or up to 304 (stride 308; fp32 8-bin form only)
+        const bool wide308 = !gemm_split_bf16_ && t->n_bins_pad > 256 && nb <= BAND_LDB3 - 4;
+        const bool wide = t->n_bins_pad <= 256 || wide308;
+        da.ldb = wide308 ? BAND_LDB3 : wide ? BAND_LDB2 : ((nb + 11) / 16 * 16 + 4);
         da.blocks = t->d_band;
         da.B = t->d_band_B;
         da.B3 = t->d_band_B3;
@@ -1829,7 +1834,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         if (do_dstamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&da.stamps), n_wg * 8 * 8));
         if (do_dstamps) PVQ_HIP(hipMemset(da.stamps, 0, n_wg * 8 * 8));
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
-        const int mt = t->band_waves == 8 ? 2 : 1;
+        const int mt = wide ? 2 : 1;
         static const int dots16_env = getenv("PVQ_DOTS_16BIN") ? atoi(getenv("PVQ_DOTS_16BIN")) : 0;   // developer knob: the 32x32x2 form
         static const int dots_f32_env = getenv("PVQ_DOTS_F32") ? atoi(getenv("PVQ_DOTS_F32")) : 0;   // developer knob
         const bool dots_split = gemm_split_bf16_ && !dots_f32_env;   // the kernel product follows the GEMM arithmetic
@@ -1839,7 +1844,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             if (dots_split) {
                 da.list = t->d_band_list + (size_t)t->band_waves * t->band_per_wave;   // the 4-wave lists
                 hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<2, 4>), grid, dim3(256), lds, stream, da);
-            } else if (dots16_env) {
+            } else if (dots16_env && !wide308) {
                 hipLaunchKernelGGL((blockdft_banddots_db<2, 8>), grid, dim3(512), lds, stream, da);
             } else {   // 8-bin blocks, 16x16x4 MFMAs
                 da.blocks = t->d_band8;
@@ -1847,18 +1852,22 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 da.list = t->d_band_list8;
                 da.per_wave = t->band_per_wave8;
                 static const int ns_env = getenv("PVQ_DOTS_NS") ? atoi(getenv("PVQ_DOTS_NS")) : 0;   // developer knob: operand ring depth
-                if (ns_env == 3)
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 3>), grid, dim3(512), lds, stream, da);
+                if (wide308)
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS, BAND_LDB3>), grid, dim3(512), lds, stream, da);
+                else if (ns_env == 3)
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 3, BAND_LDB2>), grid, dim3(512), lds, stream, da);
                 else if (ns_env == 6)
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 6>), grid, dim3(512), lds, stream, da);
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 6, BAND_LDB2>), grid, dim3(512), lds, stream, da);
                 else
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS>), grid, dim3(512), lds, stream, da);
+                    hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS, BAND_LDB2>), grid, dim3(512), lds, stream, da);
             }
         } else {
-            if (dots_split)
+            if (dots_split) {
+                da.list = t->d_band_list + (size_t)t->band_waves * t->band_per_wave;   // the 4-wave lists
                 hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<1, 4>), grid, dim3(256), lds, stream, da);
-            else
-                hipLaunchKernelGGL((blockdft_banddots_db<1, 4>), grid, dim3(256), lds, stream, da);
+            } else {
+                hipLaunchKernelGGL((blockdft_banddots_db<1, 8>), grid, dim3(512), lds, stream, da);
+            }
         }
         slot_end(SLOT_BLOCKDFT_DOTS, stream);
         if (do_dstamps) {
