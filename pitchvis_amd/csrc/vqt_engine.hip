@@ -754,7 +754,7 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     const int npad = (a.n_bins + 63) / 64 * 64;
     const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
     const size_t lds_gen = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
-    // bins per lane: 4 (<= 256 bins), 8 (<= 512), 12 (<= 768) or 16 (<= 1024)
+    // bins per lane: 4 (<= 256 bins), 8 (<= 512), 12 (<= 768) or 16 (<= 1024); the lean kernel also has 6 (<= 384)
     auto launch_generic = [&](int g, const uint8_t* flags) {
         if (a.n_bins <= 256)
             hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
@@ -778,11 +778,13 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     using std::integral_constant;
     if (a.dist > 1) {
         if (a.n_bins <= 256) launch_lean(integral_constant<int, 4>{}, std::true_type{});
+        else if (a.n_bins <= 384) launch_lean(integral_constant<int, 6>{}, std::true_type{});
         else if (a.n_bins <= 512) launch_lean(integral_constant<int, 8>{}, std::true_type{});
         else if (a.n_bins <= 768) launch_lean(integral_constant<int, 12>{}, std::true_type{});
         else launch_lean(integral_constant<int, 16>{}, std::true_type{});
     } else {
         if (a.n_bins <= 256) launch_lean(integral_constant<int, 4>{}, std::false_type{});
+        else if (a.n_bins <= 384) launch_lean(integral_constant<int, 6>{}, std::false_type{});
         else if (a.n_bins <= 512) launch_lean(integral_constant<int, 8>{}, std::false_type{});
         else if (a.n_bins <= 768) launch_lean(integral_constant<int, 12>{}, std::false_type{});
         else launch_lean(integral_constant<int, 16>{}, std::false_type{});
