@@ -38,7 +38,7 @@ struct PeakParamsDev {
 // bytes of LDS scratch one wave needs besides the frame itself
 __host__ __device__ inline size_t peaks_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return n /*cand*/ + n /*plist: n/2 u16*/ + (dist > 1 ? 2 * n /*keep[2]*/ + 2 * n * sizeof(uint16_t) /*list+order*/ : 0);
+    return n /*cand*/ + n /*plist: n/2 u16*/ + (dist > 1 ? 2 * n /*keep[2]*/ + 2 * n /*compacted candidate list: n/2 + 1 u16*/ : 0);
 }
 
 __device__ __forceinline__ float pk_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -170,35 +170,8 @@ __device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParam
     }
 }
 
-// scipy-style greedy distance suppression among candidates with x >= min_height (only for
-// dist > 1, e.g. 84 bins/octave).  Serial on one lane: the candidate list is short.
-__device__ inline void pk_distance_filter(const float* x, int n, const uint8_t* cand, float min_height, int dist,
-                                          uint8_t* keep, uint16_t* list, uint16_t* order) {
-    int np = 0;
-    for (int i = 0; i < n; ++i) {
-        keep[i] = 0;
-        if (cand[i] && x[i] >= min_height) list[np++] = (uint16_t)i;
-    }
-    for (int a = 0; a < np; ++a) order[a] = (uint16_t)a;
-    for (int a = 1; a < np; ++a) {  // stable insertion sort, ascending height
-        const uint16_t t = order[a];
-        int b = a;
-        while (b > 0 && x[list[order[b - 1]]] > x[list[t]]) {
-            order[b] = order[b - 1];
-            --b;
-        }
-        order[b] = t;
-    }
-    for (int a = 0; a < np; ++a) keep[list[a]] = 1;
-    for (int a = np - 1; a >= 0; --a) {
-        const int j = order[a];
-        if (!keep[list[j]]) continue;
-        for (int b = j - 1; b >= 0 && (int)list[j] - (int)list[b] < dist; --b) keep[list[b]] = 0;
-        for (int b = j + 1; b < np && (int)list[b] - (int)list[j] < dist; ++b) keep[list[b]] = 0;
-    }
-}
-
-// The same greedy distance suppression as pk_distance_filter, evaluated by the whole wave.  Sequentially, candidates
+// scipy-style greedy distance suppression among the candidates with x >= min_height (only for dist > 1, e.g. 84 bins per
+// octave), evaluated by the whole wave.  Sequentially (find_peaks / scipy _select_by_peak_distance), candidates
 // are visited from the highest to the lowest (ties: the later position first) and a visited candidate that is still
 // kept removes every other candidate closer than `dist`.  Equivalently, a candidate is kept iff no higher-priority
 // candidate within `dist` is kept: decided in rounds — a candidate whose higher-priority neighbours are all decided
@@ -288,7 +261,7 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.dist > 1) {
-        uint16_t* dl = reinterpret_cast<uint16_t*>(keep1 + npad);   // the area the serial filter used for its sort lists
+        uint16_t* dl = reinterpret_cast<uint16_t*>(keep1 + npad);   // compacted candidate list
         pk_distance_wave(x, n, cand, a.bass_min_height, a.dist, keep0, dl, lane);
         pk_distance_wave(x, n, cand, a.peak_min_height, a.dist, keep1, dl, lane);
     }
