@@ -348,7 +348,7 @@ constexpr int PK_WAVES = 4;
 // Common case (min_distance <= 1 and no plateau peak in the frame): the lean routine.  A frame it
 // cannot take is flagged for peaks_frames_generic, which is launched right behind it.
 template <int NK, bool DISTANCE>
-__global__ __launch_bounds__(PK_WAVES * 64, NK <= 8 ? 8 : 4) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(NK <= 8 ? 7 : 4, 8))) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
                                                                        uint8_t* __restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
