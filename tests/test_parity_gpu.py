@@ -293,3 +293,54 @@ def test_full_size_properties(algo):
         wcx = ov.calculate_vqt_instant_complex(x)[None]; wdb = ov.calculate_vqt_instant_in_db(x)[None]
         assert_parity(db[f:f + 1], cx[f:f + 1], wdb, wcx, xpeak=np.array([np.abs(x).max()]), sr=op.sr)
     assert torch.isfinite(d_db).all() and (d_db >= 0).all() and (d_db <= 60.0).all()
+
+
+@pytest.mark.parametrize("hop", [64, 128, 512, 1024])
+def test_blockdft_other_hops(hop):
+    """Block-DFT path at other power-of-two hops: 64 makes the longest window 256 blocks (two-level tree), 1024 makes
+    the shortest window a single block (no tree level at all); block-DFT == FFT path == oracle."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    nf, n_lead = 300, 777
+    pcm = white_noise(n_lead + hop * nf, 4242 + hop)
+    for algo in (P.ALGO_BLOCKDFT, "blockdft_bf16x3"):
+        _set_algo(v, algo)
+        db, cx = run_gpu(v, pcm, hop, nf, n_lead)
+        assert v.last_algo() == P.ALGO_BLOCKDFT
+        wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
+        xp = input_peak(pcm, hop, nf, n_lead, v.window_union)
+        assert_parity(db, cx, wdb, wcx, xpeak=xp, sr=op.sr)
+
+
+@pytest.mark.parametrize("hop", [64, 256])
+def test_blockdft_more_than_one_sub_batch(hop):
+    """More frames than one 65 536-frame sub-batch (the workspace, the stream rebasing and — at hop 64 — the partial-sum
+    buffer of the two-level tree are reused per sub-batch): frames around the seam and at the end against the FFT path
+    and the oracle."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    nf, n_lead = 65536 + 700, 5
+    pcm = white_noise(n_lead + hop * nf, 99 + hop)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    outs = {}
+    for algo in (P.ALGO_BLOCKDFT, P.ALGO_FFT):
+        _set_algo(v, algo)
+        d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
+        v.calculate_batch_db_device(d_pcm, hop, nf, d_db, n_lead=n_lead, d_out_cplx=d_cx); torch.cuda.synchronize()
+        assert v.last_algo() == algo
+        outs[algo] = (d_db, d_cx)
+    sel = np.concatenate([np.arange(65536 - 300, 65536 + 300), np.arange(nf - 40, nf), np.arange(0, 40)])
+    a = outs[P.ALGO_BLOCKDFT][1][sel].cpu().numpy().view(np.complex64)[..., 0]
+    b = outs[P.ALGO_FFT][1][sel].cpu().numpy().view(np.complex64)[..., 0]
+    xp = input_peak(pcm, hop, nf, n_lead, v.window_union)[sel]
+    fmax = np.maximum(np.abs(b).max(axis=1, keepdims=True), 0.01 * np.sqrt(op.sr) * xp[:, None])
+    assert (np.abs(a - b) / fmax).max() <= 1e-5
+    for f in (65535, 65536, 65537, nf - 1):
+        end = n_lead + (f + 1) * hop
+        beg = max(end - op.n_fft, 0)
+        x = np.zeros(op.n_fft, np.float32); x[op.n_fft - (end - beg):] = pcm[beg:end]
+        wcx = ov.calculate_vqt_instant_complex(x)[None]; wdb = ov.calculate_vqt_instant_in_db(x)[None]
+        db = outs[P.ALGO_BLOCKDFT][0][f:f + 1].cpu().numpy(); cx = outs[P.ALGO_BLOCKDFT][1][f:f + 1].cpu().numpy().view(np.complex64)[..., 0]
+        assert_parity(db, cx, wdb, wcx, xpeak=np.array([np.abs(x).max()]), sr=op.sr)
