@@ -106,6 +106,12 @@ struct BlockDftTables {
     float* d_P = nullptr;  size_t p_cap = 0;   // workspace
     float2* d_X = nullptr; size_t x_cap = 0;
     float2* d_Y = nullptr; size_t y_cap = 0;   // 64-block partial sums (windows of more than 64 blocks)
+    // frame-stripe tile order of the fused kernels, built per (frames, tile rows) and kept for the next launch
+    struct TileList {
+        int4* d = nullptr; size_t cap = 0;
+        int nf = -1, bm = 0, blocks = 0;
+    } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
+    int tile_list_next = 0;
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -126,6 +132,8 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_P) (void)hipFree(t->d_P);
     if (t->d_X) (void)hipFree(t->d_X);
     if (t->d_Y) (void)hipFree(t->d_Y);
+    for (auto& tl : t->tile_lists)
+        if (tl.d) (void)hipFree(tl.d);
     delete t;
 }
 
@@ -176,6 +184,7 @@ struct GemmTreeArgs {
     long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
     int n_groups;
     int blk_off[9];           // first block of each group (blocks of group g: n_tiles_g * mt8_g)
+    const int4* tile_list;    // optional: (group, column tile in the group, first frame, -) per workgroup — frame-stripe order, see launch
     const BlockGroup* groups;
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
@@ -197,6 +206,16 @@ struct FusedTile {
 template <int BM = FT_BM>
 __device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
     FusedTile t;
+    if (a.tile_list) {
+        const int4 e = a.tile_list[blockIdx.x];
+        t.G = a.groups[e.x];
+        t.S = BM - t.G.nb_f + 1;
+        t.nfr = a.n_frames + t.G.nb - t.G.nb_f;
+        t.ntl = e.y;
+        t.f0 = e.z;
+        t.nt = t.G.tile0 + t.ntl;
+        return t;
+    }
     int g = 0;
     while (g + 1 < a.n_groups && (int)blockIdx.x >= a.blk_off[g + 1]) ++g;
     t.G = a.groups[g];
@@ -1721,6 +1740,52 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 off += t->groups[g].n_tiles * mt8;
             }
             for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
+            // Frame-stripe order (developer knob PVQ_TILE_ORDER=0 keeps the group-major order above): the stream is cut into
+            // stripes of 2 048 frames, stripe s belongs to XCD s & 7 (workgroup b runs on XCD b & 7), and an XCD takes its
+            // stripes in order, within a stripe every group's row tiles with all their column tiles.  All five window groups
+            // then read a stripe's PCM rows from that XCD's L2 while they are resident (once per stripe, not once per group).
+            static const int tile_order_env = getenv("PVQ_TILE_ORDER") ? atoi(getenv("PVQ_TILE_ORDER")) : 1;
+            fa.tile_list = nullptr;
+            if (tile_order_env) {
+                BlockDftTables::TileList* tl = nullptr;
+                for (auto& c : t->tile_lists)
+                    if (c.nf == (int)nf && c.bm == fused_bm) tl = &c;
+                if (!tl) {
+                    tl = &t->tile_lists[t->tile_list_next];
+                    t->tile_list_next ^= 1;
+                    static const int fs_env = getenv("PVQ_TILE_FS") ? atoi(getenv("PVQ_TILE_FS")) : 2048;   // developer knob
+                    const int FS = fs_env;
+                    std::vector<std::vector<int4>> q(8);
+                    for (int g = 0; g < t->n_groups; ++g) {
+                        const BlockGroup& G = t->groups[g];
+                        const int S = fused_bm - G.nb_f + 1;
+                        const int rows_g = (int)nf + G.nb - G.nb_f;
+                        for (int f0 = 0; f0 < rows_g; f0 += S)
+                            for (int ntl = 0; ntl < G.n_tiles; ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
+                    }
+                    size_t L = 0;
+                    for (auto& v : q) {
+                        std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });   // by stripe; (group, row tile, column tile) order kept
+                        L = std::max(L, v.size());
+                    }
+                    std::vector<int4> list(8 * L, make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
+                    for (int x = 0; x < 8; ++x)
+                        for (size_t i = 0; i < q[x].size(); ++i) list[i * 8 + x] = q[x][i];
+                    if (tl->cap < list.size()) {
+                        if (tl->d) PVQ_HIP(hipFree(tl->d));
+                        tl->d = nullptr; tl->cap = 0;
+                        PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&tl->d), list.size() * sizeof(int4)));
+                        tl->cap = list.size();
+                    }
+                    PVQ_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read this slot
+                    PVQ_HIP(hipMemcpy(tl->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
+                    tl->nf = (int)nf;
+                    tl->bm = fused_bm;
+                    tl->blocks = (int)list.size();
+                }
+                fa.tile_list = tl->d;
+                off = tl->blocks;
+            }
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
             fa.Et = t->d_Et;
