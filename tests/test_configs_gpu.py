@@ -206,3 +206,30 @@ def test_unfused_fallback_stages_in_a_subprocess():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "UNFUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["default_22k_588", "bench_48k_252", "bench_48k_288", "hires_96k_360", "hires_96k_840", "serial_22k_180"])
+def test_same_input_same_output_every_geometry(name):
+    """Reference convention: same input => same output.  Three runs of the whole path per geometry and
+    arithmetic, every output compared bit for bit (scripts/dev_soak.py is the long version of this)."""
+    pp, op = get_geom(name)
+    hop = 128 if op.sr > 90000 else 256
+    nf, n_lead = 6000, 321
+    d_pcm = torch.from_numpy(white_noise(n_lead + hop * nf, 31)).cuda()
+    for prec in (P.GEMM_F32, P.GEMM_BF16X3):
+        v = P.Vqt.new(pp, 0)
+        v.set_algo(P.ALGO_BLOCKDFT); v.set_gemm_precision(prec)
+        words = (v.n_bins + 31) // 32
+        ref = None
+        for _ in range(3):
+            d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
+            d_mask = torch.zeros((nf, words), dtype=torch.int32, device="cuda"); d_cnt = torch.zeros(nf, dtype=torch.int32, device="cuda")
+            d_c = torch.zeros((nf, 64), device="cuda"); d_s = torch.zeros((nf, 64), device="cuda")
+            v.calculate_batch_db_device(d_pcm, hop, nf, d_db, n_lead=n_lead, d_out_cplx=d_cx)
+            v.analyze_batch_device(d_db, nf, d_mask, d_cnt, d_c, d_s, 64)
+            torch.cuda.synchronize()
+            cur = (d_db, d_cx, d_mask, d_cnt, d_c, d_s)
+            if ref is None:
+                ref = cur
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(ref, cur)), (name, prec)
