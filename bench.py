@@ -9,10 +9,13 @@ BASELINE.json configs[1], "65 536-hop batch of 48 kHz mono white noise", geometr
 VqtParameters{sr 48000, n_fft 32768, range{55 Hz, 7 oct, 36 bins/oct}, sparsity 0.999, Q 1.6,
 gamma 7.68}, hop 256, 252 bins, fp32.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the hop stream shards into
-contiguous frame ranges, one per rank, each carrying its window-union halo; kernel tables are
-replicated; there is no collective on the data path.  Weak scaling: every rank
-processes F frames, value = N*F*K / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU) runs BASELINE.json configs[2]: ONE
+hop stream of N x 131 072 hops (1 M hops at N = 8) of white noise, seed 0x5EED0003, generated
+identically on every rank, geometry 8 octaves x 36 = 288 bins, hop 256; rank r takes the
+contiguous frame range plan_shard gives it together with its real window-union halo (the
+16 128 samples before its first hop); kernel tables are replicated; there is no collective on
+the data path.  Weak scaling: every rank processes F frames,
+value = N*F*K / max-over-ranks time.
 
 Rank 0 prints ONE JSON line.
 """
@@ -28,14 +31,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# SURVEY.md §8(d), BASELINE.md §2 — per-frame algorithmic work of the 48 kHz / 7x36 geometry
-F_ALG_FLOP_PER_FRAME = 1.12e6       # 5 rFFTs (2.5 N log2 N) + 8 flop per kernel non-zero + dB/peaks
-B_ALG_BYTES_PER_FRAME = 2064.0      # hop*4 new input + 252*4 dB out + 8*4 peak mask
+# SURVEY.md §8(d), BASELINE.md §2 — per-frame algorithmic work: FFT-route flop (rFFTs at 2.5 N log2 N + 8 flop per kernel
+# non-zero + dB/peaks) and compulsory bytes (hop*4 new input + n_bins*4 dB out + ceil(n_bins/32)*4 peak mask)
+WORKLOADS = {
+    # BASELINE configs[1]: the single-GPU bench line
+    1: dict(octaves=7, n_bins=252, frames=65536, seed=0x5EED0001, f_alg=1.12e6, b_alg=2064.0,
+            name="BASELINE configs[1]: {F}-hop batch of 48 kHz mono white noise per GPU, hop 256, "
+                 "VqtParameters{{sr 48000, n_fft 32768, 55 Hz, 7 oct x 36 = 252 bins, sparsity 0.999, "
+                 "Q 1.6, gamma 7.68}}; PCM -> VQT dB frames -> peaks (mask+count+continuous)"),
+    # BASELINE configs[2]: the sharded multi-GPU case
+    2: dict(octaves=8, n_bins=288, frames=131072, seed=0x5EED0003, f_alg=1.14e6, b_alg=2212.0,
+            name="BASELINE configs[2]: one {T}-hop stream of 48 kHz mono white noise (seed 0x5EED0003) sharded over {N} GPUs, "
+                 "{F} hops per GPU with their window-union halo, hop 256, VqtParameters{{sr 48000, n_fft 32768, 55 Hz, "
+                 "8 oct x 36 = 288 bins, sparsity 0.999, Q 1.6, gamma 7.68}}; PCM -> VQT dB frames -> peaks (mask+count+continuous)"),
+}
 PEAK_FP32_TFLOPS = 157.3            # MI355X fp32 dense MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split form spends 6 bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0               # HBM3E spec peak
 
-SR, HOP, N_BINS = 48000.0, 256, 252
+SR, HOP = 48000.0, 256
 
 
 def _cpu_worker(args):
@@ -93,7 +107,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=65536, help="frames (hops) per GPU per step")
+    ap.add_argument("--frames", type=int, default=0, help="frames (hops) per GPU per step (default: 65 536 at N = 1, 131 072 at N > 1)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2],
+                    help="BASELINE config to run: 1 (252 bins, the N = 1 default) or 2 (288 bins, one sharded stream: the N > 1 default)")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "blockdft"])
     ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the block-DFT GEMM / kernel product: fp32 MFMA (default, the library default) or the exact "
@@ -122,7 +138,7 @@ def main():
     import __graft_entry__ as entry
     entry.build()
     import pitchvis_amd as P
-    from pitchvis_amd.sharding import plan_shard
+    from pitchvis_amd.sharding import global_stream, local_pcm, plan_shard
 
     device_index = local_rank % max(torch.cuda.device_count(), 1)   # identity on an N-GPU node
     torch.cuda.set_device(device_index)
@@ -130,19 +146,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
-    params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, 7, 36))
+    W = WORKLOADS[args.config or (2 if world > 1 else 1)]
+    N_BINS = W["n_bins"]
+    F_ALG_FLOP_PER_FRAME, B_ALG_BYTES_PER_FRAME = W["f_alg"], W["b_alg"]
+    params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, W["octaves"], 36))
     vqt = P.Vqt.new(params, device=device_index)
     vqt.set_algo({"auto": P.ALGO_AUTO, "fft": P.ALGO_FFT, "blockdft": P.ALGO_BLOCKDFT}[args.algo])
     vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
     assert vqt.n_bins == N_BINS
 
-    # this rank's shard of a world*F-frame stream: its hops plus the window-union halo
-    F = args.frames
+    # this rank's shard of ONE world*F-frame stream: its hops plus the window-union halo that precedes them.  The stream
+    # is generated with the same seed on every rank (Philox: identical values on every device) and sliced, so the ranks
+    # really hold consecutive pieces of one signal, halos included.
+    F = args.frames or W["frames"]
     shard = plan_shard(world * F, HOP, vqt.window_union, rank, world)
-    n_local = shard.sample_end - shard.sample_begin
-    g = torch.Generator(device="cuda")
-    g.manual_seed(0x5EED0001 + rank)
-    d_pcm = (torch.rand(n_local, device="cuda", generator=g) - 0.5) * 0.5   # uniform [-0.25, 0.25)
+    assert shard.n_frames == F
+    d_stream = global_stream(W["seed"], world * F * HOP, "cuda")
+    d_pcm = local_pcm(d_stream, shard)
+    del d_stream
+    torch.cuda.empty_cache()
     d_db = torch.empty((F, N_BINS), device="cuda", dtype=torch.float32)
     words = (N_BINS + 31) // 32
     max_peaks = 64
@@ -173,6 +195,8 @@ def main():
     kernel_ms = vqt.last_kernel_ms()
     kernel_n = vqt.last_kernel_launches()
     fpl = vqt.last_frames_per_launch()
+    gemm_flop = vqt.last_gemm_flop()     # flop the matrix instructions of one GEMM launch issue (tiles x 256 x 64 x depth x 2)
+    sclk_mhz = vqt.last_sclk_mhz()       # shader clock inside the GEMM kernel's K loop, sampled during the timed launches
     vqt.set_profiling(False)
     # the other GEMM arithmetic, same workload, reported beside the headline (rank-local, not part of `value`)
     other = "f32" if args.gemm == "bf16x3" else "bf16x3"
@@ -201,22 +225,24 @@ def main():
         # dominant kernel = largest total GPU time; one launch of it processes `fpl` frames
         dom = max(kernel_ms.items(), key=lambda kv: kv[1] * kernel_n.get(kv[0], 1))
         dom_s = dom[1] * 1e-3
-        tflops = F_ALG_FLOP_PER_FRAME * fpl / dom_s / 1e12
+        alg_tflops = F_ALG_FLOP_PER_FRAME * fpl / dom_s / 1e12
         gpu_ms_per_step = sum(kernel_ms[k] * kernel_n.get(k, 0) for k in kernel_ms) / args.steps
         split = args.gemm == "bf16x3" and vqt.last_algo() == P.ALGO_BLOCKDFT
         peak = PEAK_BF16_TFLOPS / 6.0 if split else PEAK_FP32_TFLOPS
-        # flop the GEMM MFMAs issue per launch: depth hop/2 (mirrored fp32 form) or hop (split-bf16), 2 real columns per
-        # spectrum column, rows = frames x 1.08 (256-row tiles advance by 257 - Nb blocks; 1.08 is the 48 kHz / hop 256 mean)
+        # roofline.achieved / frac: what the dominant kernel's matrix instructions EXECUTE per second (their flop per
+        # launch, counted by the library from its tile list: tiles x 256 rows x 64 real columns x depth x 2, padding
+        # columns and recomputed rows included) over the kernel's whole duration (K loop + tree + store), against the
+        # dense fp32 MFMA peak.  It cannot exceed 1 and is reproducible from profiles/: SQ_INSTS_MFMA x 4096 / kernel time.
         exec_tflops = None
-        if "blockdft_gemm" in kernel_ms and vqt.blockdft_columns():
-            depth = HOP if split else HOP // 2
-            exec_tflops = round(2.0 * depth * 2 * vqt.blockdft_columns() * fpl * 1.08 / (kernel_ms["blockdft_gemm"] * 1e-3) / 1e12, 2)
+        if dom[0] == "blockdft_gemm" and gemm_flop > 0:
+            exec_tflops = gemm_flop / dom_s / 1e12
+        achieved = exec_tflops if exec_tflops is not None else alg_tflops
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == fpl:
+                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == fpl and tj.get("n_bins", 252) == N_BINS:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -234,51 +260,52 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: {F}-hop batch of 48 kHz mono white noise per GPU, hop 256, "
-                            "VqtParameters{sr 48000, n_fft 32768, 55 Hz, 7 oct x 36 = 252 bins, sparsity 0.999, "
-                            "Q 1.6, gamma 7.68}; PCM -> VQT dB frames -> peaks (mask+count+continuous)",
+                "workload": W["name"].format(F=F, T=world * F, N=world),
                 "frames_per_gpu_per_step": F,
                 "hop": HOP,
                 "n_bins": N_BINS,
                 "algo": {P.ALGO_FFT: "fft", P.ALGO_BLOCKDFT: "blockdft"}.get(vqt.last_algo(), "auto"),
                 "gemm_arith": ("fp32 operands as 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate "
                                "(error at fp32 rounding level, same parity bars)" if split else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
-                "sharding": f"frames x{world}, halo {vqt.window_union - HOP} samples, no collective",
+                "sharding": f"one stream, frames x{world}, halo {vqt.window_union - HOP} samples per shard, no collective",
             },
             "roofline": {
-                # binding roof of this path is fp32 arithmetic (dense fp32 MFMA peak = fp32 vector peak);
-                # the HBM view required by BASELINE.json is given alongside (<<1 %).
+                # the binding roof of this path is fp32 matrix arithmetic (dense fp32 MFMA peak = fp32 vector peak);
+                # the HBM view BASELINE.json asks for is given alongside (a few % of 8 TB/s).
                 "bound": "mfma",
                 "kernel": dom[0],
-                "achieved": round(tflops, 3),
+                "achieved": round(achieved, 3),
                 "peak": round(peak, 1),
                 "unit": "TFLOP/s",
-                "frac": round(tflops / peak, 5),
+                "frac": round(achieved / peak, 5),
                 "traffic": traffic,
+                "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
+                "executed_flop_per_launch": gemm_flop if exec_tflops is not None else None,
+                # the FFT-route count of SURVEY 8d for the same frames, kept apart: the block-DFT path does not execute it
                 "alg_flop_per_frame": F_ALG_FLOP_PER_FRAME,
-                "note": "achieved = algorithmic fp32 flop (FFT-route count, SURVEY 8d) x frames per launch / mean launch time of "
-                        "the kernel with the largest GPU time; peak = dense fp32 MFMA peak (157.3) for the fp32 GEMM, or the "
-                        "dense bf16 MFMA peak / 6 (2500 / 6 = 416.7 fp32-equivalent) for the split-bf16 GEMM.  The block-DFT "
-                        "path executes far fewer flop than the FFT-route count (a hop block is transformed once for the up to 64 "
-                        "frames that share it, and the fp32 form evaluates the hop DFT about the block centre as two half-depth "
-                        "real GEMMs), so this contract figure can exceed 1; the matrix-pipe utilisation is executed_frac = "
-                        "executed_gemm_tflops / peak (flop the MFMAs of the dominant kernel actually issue, incl. the 1.08x row "
-                        "recomputation of the fused tiles, over the whole kernel: K loop + tree + store).  DESIGN.md 4-5",
+                "alg_tflops": round(alg_tflops, 3),
+                "alg_flop_ratio": round(F_ALG_FLOP_PER_FRAME * fpl / gemm_flop, 4) if exec_tflops is not None else None,
+                "note": "achieved = flop issued by the matrix instructions of the kernel with the largest GPU time (the fused GEMM + "
+                        "tree: its tiles x 256 rows x 64 real columns x hop/2 x 2) / its mean launch time, HIP events on the launch "
+                        "stream; frac = achieved / the dense fp32 MFMA peak (157.3; 2500 / 6 fp32-equivalent for the split-bf16 "
+                        "GEMM) = the fraction of the matrix pipe's time the kernel keeps it busy.  alg_tflops divides the FFT-route "
+                        "flop count of SURVEY 8d (what the reference's algorithm would execute) by the same time; alg_flop_ratio = "
+                        "that count / the executed one (> 1: a hop block is transformed once for all frames that share it, only the "
+                        "columns the kernel reads, as two half-depth real GEMMs).  sclk_mhz: shader clock sampled inside the "
+                        "kernel's K loop during the timed launches (the chip lowers it under MFMA load).  DESIGN.md 4-5",
                 "frames_per_launch": fpl,
                 "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "launches_per_step": {k: kernel_n.get(k, 0) // args.steps for k in kernel_ms},
                 "gpu_ms_per_step_all_kernels": round(gpu_ms_per_step, 4),
-                "executed_gemm_tflops": exec_tflops,
-                "executed_frac": round(exec_tflops / peak, 5) if exec_tflops else None,
-                # whole path (all kernels of a step) against the same fp32 roof
-                "path_tflops": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12, 3),
-                "path_frac": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12 / peak, 5),
+                # whole path (all kernels of a step) against the FFT-route count: the algorithmic view, may exceed 1
+                "path_alg_tflops": round(F_ALG_FLOP_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e12, 3),
                 "hbm": {
-                    "achieved": round(B_ALG_BYTES_PER_FRAME * fpl / dom_s / 1e9, 3),
+                    "achieved": round(B_ALG_BYTES_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e9, 3),
                     "peak": PEAK_HBM_GBS,
                     "unit": "GB/s",
-                    "frac": round(B_ALG_BYTES_PER_FRAME * fpl / dom_s / 1e9 / PEAK_HBM_GBS, 6),
+                    "frac": round(B_ALG_BYTES_PER_FRAME * F / (gpu_ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
                     "alg_bytes_per_frame": B_ALG_BYTES_PER_FRAME,
+                    "note": "algorithmic bytes of a step / GPU time of all its kernels",
                 },
             },
         }

@@ -7,8 +7,10 @@
  * that re-exposes `Vqt` / `VqtParameters` / `VqtError` over these symbols is shown in
  * INTEGRATION.md.
  *
- * Conventions: plain pointers and sizes, caller-allocated outputs, no exceptions cross the ABI,
- * every fallible call returns a pvq_status.  A handle is NOT thread-safe (the reference takes
+ * Conventions: plain pointers and sizes, caller-allocated outputs, no exceptions cross the ABI
+ * (every entry point catches: where the reference panics in kernel construction, vqt.rs:785-792,
+ * the call returns PVQ_ERR_INVALID_ARG with the reference's panic text; std::bad_alloc and the like
+ * become PVQ_ERR_INTERNAL), every fallible call returns a pvq_status.  A handle is NOT thread-safe (the reference takes
  * `&mut self`, vqt.rs:866); distinct handles are independent (one per worker thread / stream,
  * as pitchvis_train/src/train.rs:146-155 does).  All compute runs on the GPU: there is no CPU
  * fallback, and every compute entry point fails with PVQ_ERR_NO_DEVICE on a handle created
@@ -24,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVQ_ABI_VERSION 1
+#define PVQ_ABI_VERSION 2
 
 /* replaces VqtParameters + VqtRange (vqt.rs:238-262, 278-331), flattened POD */
 typedef struct pvq_vqt_params {
@@ -47,7 +49,9 @@ typedef enum pvq_status {
     PVQ_ERR_INVALID_ARG = 4,
     PVQ_ERR_NO_DEVICE = 5,            /* handle has no GPU context (created with device_id < 0) */
     PVQ_ERR_DEVICE = 6,               /* a HIP call failed; see pvq_last_error() */
-    PVQ_ERR_UNSUPPORTED = 7           /* geometry outside what the kernels support */
+    PVQ_ERR_UNSUPPORTED = 7,          /* geometry outside what the kernels support */
+    PVQ_ERR_INTERNAL = 8,             /* out of host memory or an unexpected C++ exception, caught at the ABI; pvq_last_error() has the text */
+    PVQ_ERR_NONFINITE_INPUT = 9       /* a NaN / Inf sample reached a frame (see pvq_vqt_input_status) */
 } pvq_status;
 
 const char *pvq_status_string(pvq_status s);
@@ -121,6 +125,17 @@ pvq_status pvq_vqt_calculate_batch_db(pvq_vqt *v, const float *pcm, size_t n_lea
 pvq_status pvq_vqt_calculate_batch_db_device(pvq_vqt *v, const float *d_pcm, size_t n_lead,
                                              size_t hop, size_t n_frames, float *d_out_db,
                                              float *d_out_cplx, void *stream);
+
+/*
+ * NaN / Inf policy.  The reference's callers never pass non-finite samples to the transform (the audio
+ * callback drops such chunks, pitchvis_audio/src/audio_desktop.rs:102-105), and the NaNs they would cause make its peak
+ * stage panic (peak_detection.rs:145 `partial_cmp().unwrap()`).  Here a non-finite sample inside one of a frame's windows
+ * raises a sticky flag on the device while the frame's dB values are computed; the frames it touches are unspecified.
+ * The synchronous host-buffer entry points (pvq_vqt_calculate_instant_db, pvq_vqt_calculate_batch_db, pvq_train_frames_db)
+ * check the flag themselves and return PVQ_ERR_NONFINITE_INPUT.  For the asynchronous device-pointer entry points call
+ * this: it waits for `stream`, returns PVQ_ERR_NONFINITE_INPUT if the flag is up (PVQ_OK otherwise) and clears it.
+ */
+pvq_status pvq_vqt_input_status(pvq_vqt *v, void *stream);
 
 /* algorithm selection for the batch path (default PVQ_ALGO_AUTO) */
 typedef enum pvq_algo {
@@ -316,6 +331,12 @@ uint32_t pvq_vqt_last_kernel_ms(pvq_vqt *v, float *out_ms, uint32_t capacity);
 /* out_n[i] = launches of kernel slot i recorded since profiling was enabled (a batch call may
  * launch a kernel once per sub-batch); out_ms above is the mean per launch */
 uint32_t pvq_vqt_last_kernel_launches(pvq_vqt *v, uint32_t *out_n, uint32_t capacity);
+/* flop issued by the matrix instructions of the last block-DFT GEMM launch (tiles x rows x columns x depth x 2, padding and
+ * recomputed rows included); 0 after a call that took the FFT path */
+double pvq_vqt_last_gemm_flop(const pvq_vqt *v);
+/* shader clock (MHz) the chip held inside the GEMM kernel's K loop during the last profiled launch: median over sampled
+ * workgroups of shader-clock ticks / 100 MHz ticks; 0 if nothing was measured.  Synchronises the device. */
+float pvq_vqt_last_sclk_mhz(pvq_vqt *v);
 /* frames one launch of the frame kernels processed in the last batch call (the sub-batch size) */
 uint32_t pvq_vqt_last_frames_per_launch(const pvq_vqt *v);
 const char *pvq_vqt_kernel_name(uint32_t slot);

@@ -63,7 +63,8 @@ class VqtParameters:
 
 # ---- vqt.rs:350-366 -------------------------------------------------------------------------
 class PvqError(RuntimeError):
-    """Any non-OK pvq_status that is not a VqtError variant."""
+    """Any non-OK pvq_status that is not a VqtError variant (status 9 = PVQ_ERR_NONFINITE_INPUT: a NaN / Inf sample
+    reached a frame; 8 = PVQ_ERR_INTERNAL; 4 = PVQ_ERR_INVALID_ARG, also where the reference would panic)."""
 
     def __init__(self, status: int, msg: str):
         self.status = status
@@ -374,6 +375,19 @@ class Vqt:
 
     def last_frames_per_launch(self) -> int:
         return int(self._L.pvq_vqt_last_frames_per_launch(self._h))
+
+    def last_gemm_flop(self) -> float:
+        """flop the matrix instructions of the last block-DFT GEMM launch issued (0 after the FFT path)"""
+        return float(self._L.pvq_vqt_last_gemm_flop(self._h))
+
+    def last_sclk_mhz(self) -> float:
+        """shader clock held inside the GEMM kernel's K loop during the last profiled launch (0: not measured)"""
+        return float(self._L.pvq_vqt_last_sclk_mhz(self._h))
+
+    def input_status(self, stream=None) -> None:
+        """NaN / Inf policy for the asynchronous entry points (include/pvq.h): waits for `stream`, raises
+        PvqError(PVQ_ERR_NONFINITE_INPUT) if a non-finite sample reached a frame since the last check."""
+        _check(self._L.pvq_vqt_input_status(self._h, _stream_handle(stream)))
 
 
 # ---- analysis.rs:35-98, 119-410: stateful per-stream analysis (host side) ---------------------------

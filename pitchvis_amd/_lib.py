@@ -27,6 +27,7 @@ EXPORTS = [
     "pvq_train_frames_db", "pvq_train_rows", "pvq_npy_write_f32", "pvq_stream_create", "pvq_stream_destroy",
     "pvq_stream_push", "pvq_stream_gain", "pvq_stream_chunk_size_ms", "pvq_stream_frame_db", "pvq_stream_read",
     "pvq_calculate_color", "pvq_led_frame", "pvq_host_alloc", "pvq_host_free",
+    "pvq_vqt_input_status", "pvq_vqt_last_gemm_flop", "pvq_vqt_last_sclk_mhz",
 ]
 
 PVQ_OK = 0
@@ -37,6 +38,8 @@ PVQ_ERR_INVALID_ARG = 4
 PVQ_ERR_NO_DEVICE = 5
 PVQ_ERR_DEVICE = 6
 PVQ_ERR_UNSUPPORTED = 7
+PVQ_ERR_INTERNAL = 8
+PVQ_ERR_NONFINITE_INPUT = 9
 
 ALGO_AUTO, ALGO_FFT, ALGO_BLOCKDFT = 0, 1, 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
@@ -183,5 +186,8 @@ def load():
     L.pvq_led_frame.restype = C.c_size_t
     L.pvq_host_alloc.argtypes = [C.c_size_t]; L.pvq_host_alloc.restype = C.c_void_p
     L.pvq_host_free.argtypes = [C.c_void_p]
+    L.pvq_vqt_input_status.argtypes = [vp, vp]; L.pvq_vqt_input_status.restype = C.c_int
+    L.pvq_vqt_last_gemm_flop.argtypes = [vp]; L.pvq_vqt_last_gemm_flop.restype = C.c_double
+    L.pvq_vqt_last_sclk_mhz.argtypes = [vp]; L.pvq_vqt_last_sclk_mhz.restype = C.c_float
     _lib = L
     return L

@@ -101,8 +101,9 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
 
     std::vector<float> lnf;
     bin_log_frequencies(plan.params, lnf);
+    const std::vector<uint32_t> status(4, 0u);
 
-    if (!upload(&t->d_lnf, lnf, msg) || !upload(&t->d_groups, t->h_groups, msg) || !upload(&t->d_tw, tw, msg) || !upload(&t->d_split_tw, split_tw, msg) ||
+    if (!upload(&t->d_status, status, msg) || !upload(&t->d_lnf, lnf, msg) || !upload(&t->d_groups, t->h_groups, msg) || !upload(&t->d_tw, tw, msg) || !upload(&t->d_split_tw, split_tw, msg) ||
         !upload(&t->d_row_ptr, row_ptr, msg) || !upload(&t->d_ent_val, ent_val, msg) ||
         !upload(&t->d_ent_col, ent_col, msg)) {
         free_device_tables(t);
@@ -121,6 +122,7 @@ void free_device_tables(DeviceTables* t) {
     if (t->d_ent_val) (void)hipFree(t->d_ent_val);
     if (t->d_ent_col) (void)hipFree(t->d_ent_col);
     if (t->d_lnf) (void)hipFree(t->d_lnf);
+    if (t->d_status) (void)hipFree(t->d_status);
     delete t;
 }
 

@@ -40,6 +40,7 @@ struct DeviceTables {
     float2* d_ent_val = nullptr;   // filter_bank values; negative_filter_bank values stored conjugated
     uint16_t* d_ent_col = nullptr; // column | 0x8000 when the entry multiplies conj(X[col])
     float* d_lnf = nullptr;        // ln(f_k) per bin (host libm, peak_detection.rs:81-86)
+    uint32_t* d_status = nullptr;  // [0]: sticky "a frame's spectrum was not finite" flag set by the dB stages (see Vqt::input_status)
     BlockDftTables* block = nullptr;
 };
 

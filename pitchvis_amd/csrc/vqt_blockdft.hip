@@ -110,8 +110,10 @@ struct BlockDftTables {
     struct TileList {
         int4* d = nullptr; size_t cap = 0;
         int nf = -1, bm = 0, blocks = 0;
+        int real = 0;   // entries that are tiles (the rest pads the eight per-XCD queues to one length)
     } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
     int tile_list_next = 0;
+    unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -134,6 +136,7 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_Y) (void)hipFree(t->d_Y);
     for (auto& tl : t->tile_lists)
         if (tl.d) (void)hipFree(tl.d);
+    if (t->d_clk) (void)hipFree(t->d_clk);
     delete t;
 }
 
@@ -189,6 +192,7 @@ struct GemmTreeArgs {
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
+    unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader-clock ticks, 100 MHz ticks) of its K loop
 };
 #define PVQ_STAMP(i) \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();
@@ -472,10 +476,21 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
         acc0[q] = 0.0f;
         acc1[q] = 0.0f;
     }
+    // the clock the chip holds under this kernel's MFMA load: shader-clock ticks over 100 MHz ticks across the K loop
+    const bool clk_me = a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0;
+    unsigned long long clk_c = 0, clk_r = 0;
+    if (clk_me) {
+        clk_c = __builtin_amdgcn_s_memtime();
+        clk_r = __builtin_amdgcn_s_memrealtime();
+    }
     if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
         fused_f32_kloop<true, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
     else
         fused_f32_kloop<false, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+    if (clk_me) {
+        a.clk[(blockIdx.x >> 6) * 2 + 0] = __builtin_amdgcn_s_memtime() - clk_c;
+        a.clk[(blockIdx.x >> 6) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r;
+    }
     PVQ_STAMP(1);
     __syncthreads();   // the E slice is dead: the P' tile takes its place
     PVQ_STAMP(4);
@@ -819,6 +834,7 @@ struct BandArgs {
     int per_wave;
     float* out_db;             // [n_frames][n_bins]
     float2* out_cplx;          // optional
+    unsigned* status;          // the handle's sticky flag word: bit 0 <- a live frame holds a non-finite power value
     unsigned long long* stamps;   // developer knob PVQ_STAMPS_DOTS: [workgroup][8] 100 MHz clock: 0 start, 1 wave 0 done with its blocks, 2 all waves done, 3 end
 };
 
@@ -907,6 +923,12 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
     auto to_db = [&](float p) { return 3.01029995663981f * __log2f(fmaxf(p, PVQ_A_MIN)) - ref_db; };
+    // non-finite input (a NaN / Inf sample inside one of the frame's windows) reaches every bin of the frame as a NaN or Inf
+    // power; fmaxf would silently turn it into the A_MIN floor, so it is flagged instead (Vqt::input_status)
+    bool bad = false;
+    auto flag = [&]() {
+        if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, 1u);
+    };
     auto in_registers = [&](auto fu_c, auto nkb_c) {
         constexpr int FU = decltype(fu_c)::value, NKB = decltype(nkb_c)::value;
         for (int fr0 = wave; fr0 < MT * 32; fr0 += NW * FU) {
@@ -915,11 +937,14 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
             for (int u = 0; u < FU; ++u) {
                 mx[u] = -3.40282347e+38f;
                 mn[u] = 3.40282347e+38f;
+                const bool live = f0 + fr0 + NW * u < a.n_frames;
 #pragma unroll
                 for (int kk = 0; kk < NKB; ++kk) {
                     const int k = lane + 64 * kk;
                     const bool in = k < a.n_bins;
-                    d[u][kk] = to_db(in ? dbs[(fr0 + NW * u) * ldb + k] : 1.0f);
+                    const float p = in ? dbs[(fr0 + NW * u) * ldb + k] : 1.0f;
+                    bad |= live && !(p <= 3.40282347e+38f);
+                    d[u][kk] = to_db(p);
                     mx[u] = fmaxf(mx[u], in ? d[u][kk] : -3.40282347e+38f);
                     mn[u] = fminf(mn[u], in ? d[u][kk] : 3.40282347e+38f);
                 }
@@ -947,10 +972,12 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
     };
     if (a.n_bins <= 256) {
         in_registers(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+        flag();
         return;
     }
     if (a.n_bins <= 512) {
         in_registers(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+        flag();
         return;
     }
     for (int fr = wave; fr < MT * 32; fr += NW) {
@@ -958,6 +985,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
         float* rowp = dbs + fr * ldb;
         float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
         for (int k = lane; k < a.n_bins; k += 64) {
+            bad |= !(rowp[k] <= 3.40282347e+38f);
             const float d = to_db(rowp[k]);
             rowp[k] = d;
             mx = fmaxf(mx, d);
@@ -973,6 +1001,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
             dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
         }
     }
+    flag();
 }
 
 template <int MT, int NW>   // 32-frame MFMA row tiles per workgroup, waves per workgroup
@@ -1313,6 +1342,21 @@ static inline float host_from_bf16(uint16_t h) {
     float f;
     std::memcpy(&f, &u, 4);
     return f;
+}
+
+// median over the sampled workgroups of the last profiled fused-GEMM launch: shader clock (MHz) held inside the K loop
+float Vqt::last_sclk_mhz() {
+    if (!dev_ || !dev_->block || !dev_->block->d_clk || dev_->block->clk_n <= 0) return 0.0f;
+    BlockDftTables* t = dev_->block;
+    std::vector<unsigned long long> h((size_t)t->clk_n * 2);
+    if (hipSetDevice(device_id_) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0.0f;
+    if (hipMemcpy(h.data(), t->d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0.0f;
+    std::vector<double> r;
+    for (int i = 0; i < t->clk_n; ++i)
+        if (h[2 * i + 1] > 0) r.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+    if (r.empty()) return 0.0f;
+    std::sort(r.begin(), r.end());
+    return (float)r[r.size() / 2];
 }
 
 uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_t)(dev_->block->n_tiles * CB_C) : 0u; }
@@ -1735,13 +1779,14 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             // 256-row tiles for the split-bf16 form: 257 - Nb complete frames per tile (1.08x row recomputation instead
             // of 1.2x) and the E^T planes staged once per 256 rows; measured 7 % faster than 128-row tiles
             const int fused_bm = bm_env != 128 ? 256 : FT_BM;
-            int off = 0;
+            int off = 0, real_tiles = 0;
             for (int g = 0; g < t->n_groups; ++g) {
                 fa.blk_off[g] = off;
                 const int S = fused_bm - t->groups[g].nb_f + 1;
                 const int rows_g = (int)nf + t->groups[g].nb - t->groups[g].nb_f;
                 const int mt8 = (((rows_g + S - 1) / S) + 7) / 8 * 8;
                 off += t->groups[g].n_tiles * mt8;
+                real_tiles += t->groups[g].n_tiles * ((rows_g + S - 1) / S);
             }
             for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
             // Frame-stripe order (developer knob PVQ_TILE_ORDER=0 keeps the group-major order above): the stream is cut into
@@ -1786,9 +1831,12 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     tl->nf = (int)nf;
                     tl->bm = fused_bm;
                     tl->blocks = (int)list.size();
+                    tl->real = 0;
+                    for (auto& v : q) tl->real += (int)v.size();
                 }
                 fa.tile_list = tl->d;
                 off = tl->blocks;
+                real_tiles = tl->real;
             }
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
@@ -1799,6 +1847,22 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.stamps = nullptr;
             if (do_stamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&fa.stamps), (size_t)off * 8 * 8 + 8));
             if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 8 * 8 + 8));
+            // flop the GEMM's matrix instructions issue in this launch: tiles x rows x 64 real columns x depth x 2
+            // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
+            last_gemm_flop_ = (double)real_tiles * fused_bm * FT_BN * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
+            fa.clk = nullptr;
+            if (profiling_ && !use_bf) {
+                const size_t need = ((size_t)off / 64 + 1) * 2 * sizeof(unsigned long long);
+                if (t->clk_cap < need) {
+                    if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
+                    t->d_clk = nullptr; t->clk_cap = 0;
+                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_clk), need));
+                    t->clk_cap = need;
+                }
+                PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
+                t->clk_n = off / 64 + 1;
+                fa.clk = t->d_clk;
+            }
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
             if (use_bf && fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
@@ -1855,6 +1919,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             ga.n_col_tiles = t->n_tiles;
             ga.p_rows = (int)rows_cap;
             const int m_tiles8 = (((n_rows + 255) / 256) + 7) / 8 * 8;
+            last_gemm_flop_ = (double)ga.n_col_tiles * ((n_rows + 255) / 256) * 256.0 * FT_BN * ((double)hop / 2) * 2.0;
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
             hipLaunchKernelGGL(blockdft_gemm_rows<256>, dim3(ga.n_col_tiles * m_tiles8), dim3(512), 0, stream, ga);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
@@ -1895,6 +1960,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.per_wave = t->band_per_wave;
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
+        da.status = dev_->d_status;
         static const char* dstamps_env = getenv("PVQ_STAMPS_DOTS");   // developer knob: dump per-workgroup phase stamps once
         static bool dstamps_done = false;
         const bool do_dstamps = dstamps_env && !dstamps_done;

@@ -31,6 +31,13 @@ namespace pvq {
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
+void set_last_error_noexcept(const char* s) noexcept {
+    try {
+        g_last_error = s ? s : "";
+    } catch (...) {
+        g_last_error.clear();
+    }
+}
 const char* get_last_error() { return g_last_error.c_str(); }
 
 #define PVQ_HIP(call)                                                                              \
@@ -192,14 +199,18 @@ __device__ __forceinline__ float wave_min(float v) {
 
 // Frame-relative dB epilogue shared by both algorithm paths.  xv: n_bins complex coefficients in
 // LDS; red: 2*(BLOCK/64) floats of LDS scratch.  Writes n_bins floats to out (global).
+// status: the handle's sticky flag word; bit 0 is raised when a coefficient of the frame is not finite (a NaN / Inf sample
+// in the frame's windows: the reference's callers drop such input, audio_desktop.rs:102-105, and peak_detection.rs:145
+// would panic on it)
 template <int BLOCK>
 __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_bins, float* __restrict__ out,
-                                            float* lds_out, int tid) {
+                                            float* lds_out, int tid, unsigned* status) {
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     constexpr int NW = BLOCK / 64;
     constexpr int PER = 4;  // supports n_bins <= 4*BLOCK
     float d[PER];
     float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
+    bool bad = false;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int k = tid + t * BLOCK;
@@ -207,6 +218,7 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
         if (k < n_bins) {
             const float2 z = xv[k];
             const float ns = z.x * z.x + z.y * z.y;
+            bad |= !(ns <= 3.40282347e+38f);
             d[t] = 10.0f * log10f(fmaxf(ns, PVQ_A_MIN)) - ref_db;
             mx = fmaxf(mx, d[t]);
             mn = fminf(mn, d[t]);
@@ -214,6 +226,7 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
     }
     mx = wave_max(mx);
     mn = wave_min(mn);
+    if (status && __builtin_amdgcn_ballot_w64(bad) != 0 && (tid & 63) == 0) atomicOr(status, 1u);
     if ((tid & 63) == 0) {
         red[tid >> 6] = mx;
         red[NW + (tid >> 6)] = mn;
@@ -262,6 +275,7 @@ struct FftArgs {
     const uint16_t* ent_col;
     float* out_db;
     float2* out_cplx;
+    unsigned* status;
 };
 
 template <int BLOCK, int E>
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
         if (a.out_cplx) {
             for (int k = tid; k < a.n_bins; k += BLOCK) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
         }
-        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, nullptr, tid);
+        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, nullptr, tid, a.status);
         __syncthreads();
     }
 }
@@ -601,6 +615,7 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     a.ent_col = dev_->d_ent_col;
     a.out_db = d_out_db;
     a.out_cplx = reinterpret_cast<float2*>(d_out_cplx);
+    a.status = dev_->d_status;
 
     const size_t lds = sizeof(float2) * ((size_t)(dev_->n_tw + (dev_->n_tw >> 4)) + 1 + dev_->max_cols + a.n_bins) +
                        sizeof(float) * 32;
@@ -625,6 +640,7 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_FFT;
     last_frames_per_launch_ = (uint32_t)n_frames;
+    last_gemm_flop_ = 0.0;
     return PVQ_OK;
 }
 
@@ -703,7 +719,7 @@ pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, 
                                        static_cast<float*>(ws_out_), nullptr, nullptr);
         if (st != PVQ_OK) return st;
         PVQ_HIP(hipMemcpy(out_db, ws_out_, n_frames * nb * sizeof(float), hipMemcpyDeviceToHost));
-        return PVQ_OK;
+        return input_status(nullptr);
     }
     // Large batches: upload, transform and download in parts on three streams, so that with page-locked host buffers
     // (pvq_host_alloc) the two PCIe directions and the kernels overlap.  Part p's frames see the parts before it as
@@ -738,7 +754,20 @@ pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, 
     }
     PVQ_HIP(hipStreamSynchronize(s_out));
     PVQ_HIP(hipStreamSynchronize(s_run));
-    return PVQ_OK;
+    return input_status(s_run);
+}
+
+pvq_status Vqt::input_status(hipStream_t stream) {
+    if (!has_device() || !dev_ || !dev_->d_status) return PVQ_OK;
+    PVQ_HIP(hipSetDevice(device_id_));
+    PVQ_HIP(hipStreamSynchronize(stream));
+    uint32_t flag = 0;
+    PVQ_HIP(hipMemcpy(&flag, dev_->d_status, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag == 0) return PVQ_OK;
+    PVQ_HIP(hipMemset(dev_->d_status, 0, sizeof flag));
+    set_last_error("non-finite sample (NaN / Inf) in the input: the affected frames are unspecified (the reference's audio "
+                   "callback drops such chunks, audio_desktop.rs:102-105; peak_detection.rs:145 would panic)");
+    return PVQ_ERR_NONFINITE_INPUT;
 }
 
 pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* out_db) {

@@ -76,6 +76,16 @@ class Vqt {
     uint32_t last_kernel_ms(float* out, uint32_t cap);
     uint32_t last_kernel_launches(uint32_t* out, uint32_t cap) const;
     uint32_t last_frames_per_launch() const { return last_frames_per_launch_; }
+    // flop issued by the matrix instructions of the last block-DFT GEMM launch (0 when the FFT path ran)
+    double last_gemm_flop() const { return last_gemm_flop_; }
+    // shader clock (MHz) measured inside the GEMM kernel's K loop during the last profiled launch (0: not measured)
+    float last_sclk_mhz();
+    // NaN / Inf policy.  The reference's callers never hand non-finite samples to the transform (the audio callback drops
+    // such chunks, pitchvis_audio/src/audio_desktop.rs:102-105) and its peak stage would panic on the NaNs they cause
+    // (peak_detection.rs:145).  Here the dB stages raise a sticky device flag when a frame's spectrum is not finite;
+    // this call waits for `stream`, returns PVQ_ERR_NONFINITE_INPUT if the flag is up and clears it.  The synchronous
+    // host-buffer entry points call it themselves.
+    pvq_status input_status(hipStream_t stream);
 
     enum KernelSlot { SLOT_FFT_FRAMES = 0, SLOT_BLOCKDFT_GEMM = 1, SLOT_BLOCKDFT_COMBINE = 2, SLOT_BLOCKDFT_DOTS = 3, SLOT_PEAKS = 4, N_SLOTS = 5 };
     static const char* slot_name(uint32_t s);
@@ -111,6 +121,7 @@ class Vqt {
     bool twiddle_fp16_ = false;
     bool gemm_split_bf16_ = false;  // default PVQ_GEMM_F32; PVQ_GEMM_BF16X3 meets the same parity bars and is ~10 % faster end to end
     uint32_t last_frames_per_launch_ = 0;
+    double last_gemm_flop_ = 0.0;
     static constexpr int kMaxTimedLaunches = 512;
     std::vector<hipEvent_t> ev_[N_SLOTS][2];  // event pool, grown on demand
     int ev_count_[N_SLOTS] = {};              // launches recorded since profiling was enabled
@@ -122,6 +133,7 @@ class Vqt {
 };
 
 void set_last_error(const std::string& s);
+void set_last_error_noexcept(const char* s) noexcept;   // for exception handlers: never throws (drops the text if it cannot be stored)
 const char* get_last_error();
 
 }  // namespace pvq

@@ -8,7 +8,6 @@
 #include "vqt_host.hpp"
 
 #include <algorithm>
-#include <cassert>
 #include <cmath>
 #include <cstdio>
 
@@ -49,7 +48,7 @@ class SmallFft {
     explicit SmallFft(uint32_t n) : n_(n), rev_(n), tw_(n / 2 ? n / 2 : 1) {
         uint32_t lg = 0;
         while ((1u << lg) < n) ++lg;
-        assert((1u << lg) == n);
+        if ((1u << lg) != n) throw PanicError("FFT length must be a power of two");
         for (uint32_t i = 0; i < n; ++i) {
             uint32_t r = 0;
             for (uint32_t b = 0; b < lg; ++b)
@@ -104,10 +103,12 @@ void calculate_filter(float sr, float sparsity_quantile, uint32_t sr_scaling, co
     const float scaled_center = (window_center - static_cast<float>(w0)) / scaling;
     const uint32_t center = trunc_sat(std::floor(scaled_center));
     const uint32_t scaled_n_fft = (w1 - w0) / sr_scaling;
-    assert(len <= scaled_n_fft);
-    assert(center >= len / 2);
+    // the reference panics here (vqt.rs:785-792); the C ABI reports the same text with PVQ_ERR_INVALID_ARG
+    if (!(len <= scaled_n_fft)) throw PanicError("assertion failed: scaled_window_length_rounded <= scaled_n_fft");
+    if (!(center >= len / 2))
+        throw PanicError("filter window must fit between the start of its group window and the common window center");
     const uint32_t begin = center - len / 2;
-    assert(begin + len <= scaled_n_fft);
+    if (!(begin + len <= scaled_n_fft)) throw PanicError("filter window must end before the end of its group window");
 
     v.assign(scaled_n_fft, cf32{0.0f, 0.0f});
     const double pi = 3.14159265358979323846;

@@ -7,10 +7,17 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 namespace pvq {
+
+// Where the reference panics (assert! / expect in vqt.rs:785-792) the host code throws this; it never leaves the
+// library: the extern "C" layer turns it into PVQ_ERR_INVALID_ARG with the reference's panic text (capi.cpp).
+struct PanicError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
 
 struct cf32 {
     float re, im;

@@ -28,3 +28,17 @@ def plan_shard(n_frames_total: int, hop: int, window_union: int, rank: int, worl
     halo = max(window_union - hop, 0)            # samples before hop_begin its first frame reads
     begin = max(hop_begin - halo, 0)
     return Shard(first, n, begin, hop_begin + n * hop, hop_begin - begin)
+
+
+def global_stream(seed: int, n_samples: int, device="cuda"):
+    """The synthetic benchmark stream: white noise uniform in [-0.25, 0.25), fp32.  Same seed => same values on every
+    rank (one Philox stream per device type), so that ranks slicing it hold consecutive pieces of ONE signal."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return (torch.rand(n_samples, device=device, generator=g) - 0.5) * 0.5
+
+
+def local_pcm(stream, shard: Shard):
+    """This rank's piece of the global stream: its hops preceded by its halo (a copy, so the stream can be freed)."""
+    return stream[shard.sample_begin:shard.sample_end].clone()

@@ -6,7 +6,7 @@ import pytest
 import oracle as O
 import pitchvis_amd as P
 from pitchvis_amd.sharding import plan_shard
-from helpers import get_geom, white_noise, mask_to_indices
+from helpers import get_geom, white_noise, mask_to_indices, report
 from synth import piano_roll, active_notes
 from test_parity_gpu import assert_parity, input_peak
 
@@ -137,7 +137,7 @@ def test_config5_polyphonic_notes():
         partials = set(int(round(m + 12 * np.log2(h))) for m in truth for h in range(1, 7))
         explained += len(det & partials); ndet += len(det)
     recall, precision, spectral_precision = tp / (tp + fn), tp / (tp + fp), explained / ndet
-    print(f"config5: note recall {recall:.3f}, note precision {precision:.3f} (overtones count as false), "
+    report("parity_evidence_r02.txt", f"# config5: note recall {recall:.3f}, note precision {precision:.3f} (overtones count as false), "
           f"peaks explained by a partial of an active note {spectral_precision:.3f}; "
           f"frames whose GPU note list differs from the oracle's: {mismatched}/{nf}")
     assert mismatched <= nf // 50          # only threshold-straddling peaks (size within tolerance of 12 dB) may differ
@@ -233,3 +233,79 @@ def test_same_input_same_output_every_geometry(name):
                 ref = cur
             else:
                 assert all(torch.equal(a, b) for a, b in zip(ref, cur)), (name, prec)
+
+
+def test_config3_full_size_shard_on_one_gpu():
+    """BASELINE configs[2] at its real per-GPU size: rank 3 of 8's shard of the 1 M-hop stream (seed 0x5EED0003, 48 kHz,
+    8 x 36 = 288 bins, hop 256): 131 072 frames with their 16 128-sample halo, exactly what bench.py --gpus 8 hands that
+    rank.  Size-independent properties (the same stream analysed without the shard cut gives the same bits around both
+    shard edges; determinism; finite, 0..60 dB) plus oracle spot frames at the edges and inside."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pitchvis_amd.sharding import global_stream, local_pcm
+    pp, op = get_geom("bench_48k_288")
+    v = P.Vqt.new(pp, 0)
+    hop, F, world, rank = 256, 131072, 8, 3
+    stream = global_stream(0x5EED0003, world * F * hop, "cuda")
+    s = plan_shard(world * F, hop, v.window_union, rank, world)
+    assert s.n_frames == F and s.n_lead == v.window_union - hop == 16128
+    d_pcm = local_pcm(stream, s)
+    words = (v.n_bins + 31) // 32
+
+    def run(pcm, nf, n_lead):
+        d_db = torch.empty((nf, v.n_bins), device="cuda")
+        d_mask = torch.zeros((nf, words), dtype=torch.int32, device="cuda")
+        d_cnt = torch.zeros(nf, dtype=torch.int32, device="cuda")
+        v.vqt_analyze_batch_device(pcm, hop, nf, d_db, d_mask, d_cnt, n_lead=n_lead)
+        torch.cuda.synchronize()
+        return d_db, d_mask, d_cnt
+
+    a = run(d_pcm, F, s.n_lead)
+    assert v.last_algo() == P.ALGO_BLOCKDFT and v.last_frames_per_launch() == 65536
+    b = run(d_pcm, F, s.n_lead)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))                                  # same input, same output
+    assert torch.isfinite(a[0]).all() and float(a[0].min()) >= 0.0 and float(a[0].max()) <= 60.0 and int(a[2].sum()) > F
+    v.input_status()
+    # the unsharded stream around both edges of the shard: 4 096 frames straddling each, with all the history they want
+    for edge in (s.first_frame, s.first_frame + F):
+        f0 = edge - 2048
+        lead = min(f0 * hop, 40000)
+        piece = stream[f0 * hop - lead:(f0 + 4096) * hop]
+        c = run(piece, 4096, lead)
+        lo, hi = max(f0, s.first_frame), min(f0 + 4096, s.first_frame + F)
+        for x, y in zip(a, c):
+            assert torch.equal(x[lo - s.first_frame:hi - s.first_frame], y[lo - f0:hi - f0])
+    # oracle spot frames
+    ov = O.OracleVqt(op)
+    host = stream[s.sample_begin:s.sample_end].cpu().numpy()
+    db = a[0].cpu().numpy()
+    mask = a[1].cpu().numpy().view(np.uint32)
+    for f in (0, 1, 65535, 65536, 99999, F - 1):
+        end = s.n_lead + (f + 1) * hop
+        beg = max(end - op.n_fft, 0)
+        x = np.zeros(op.n_fft, np.float32)
+        x[op.n_fft - (end - beg):] = host[beg:end]
+        wdb = ov.calculate_vqt_instant_in_db(x)
+        assert np.abs(db[f] - wdb).max() <= 1e-2 and np.abs(db[f] - wdb)[wdb > wdb.max() - 20].max() <= 2e-3
+        assert np.array_equal(mask_to_indices(mask[f], v.n_bins), O.find_peaks_split(db[f], 36))
+
+
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """bench.py's N > 1 path end to end on the one-GPU box: two ranks (both on cuda:0, gloo for the barrier and the
+    max-over-ranks reduce) run BASELINE configs[2]'s geometry on two consecutive shards of one stream.  The 8-GPU RCCL run
+    is the driver's; this checks that the line it will get is well-formed and names the right workload."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "16384", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["n_bins"] == 288 and "configs[2]" in j["config"]["workload"]
+    assert j["value"] > 0 and 0 < j["roofline"]["frac"] <= 1.0 and j["roofline"]["bound"] == "mfma"
+    assert abs(j["value"] - 2 * 16384 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3

@@ -149,3 +149,67 @@ def test_pinned_host_buffers():
     pin = P.PinnedArray((pcm.size,))
     pin.array[:] = pcm
     assert np.array_equal(v.calculate_batch_db(pin.array, hop, nf, n_lead=1000), want)
+
+
+def test_serial_led_frames_from_batched_gpu_peaks():
+    """SURVEY 8f row 4 on the GPU: pitchvis_serial's loop (main.rs:198-220: ring buffer -> VQT -> AnalysisState::preprocess ->
+    update_serial) as a batch.  The serial geometry (main.rs:17-39: 22 050 Hz, 5 x 36 bins, Q 1.8), one frame per 1/30 s.
+    (a) stateless: pvq_vqt_analyze_batch_device's peaks_continuous -> pvq_led_frame, against oracle/consumers.py's
+        update_serial restatement fed with the oracle's peak pipeline on the same GPU dB frame: the same bytes, except that a
+        (size / max) * 254 product sitting on an integer boundary may quantise one level apart (centre / size carry the
+        1e-4-bin / 2e-3-dB tolerance of tests/test_peaks_gpu.py);
+    (b) stateful, as the reference runs it: GPU dB frames -> the product's host AnalysisState -> pvq_led_frame, against
+        oracle/analysis_state.py -> oracle update_serial."""
+    torch = pytest.importorskip("torch")
+    from oracle.analysis_state import OracleAnalysisState
+    from pitchvis_amd import consumers as PC
+    from helpers import get_geom, white_noise
+    from synth import piano_roll
+    pp, op = get_geom("serial_22k_180")
+    v = P.Vqt.new(pp, 0)
+    n, bpo = v.n_bins, op.buckets_per_octave
+    pcm, _ = piano_roll(op.sr, 8.0, 21)
+    pcm = (pcm * 2.0 + white_noise(pcm.size, 21, amp=0.004)).astype(np.float32)
+    hop = int(op.sr) // 30                                   # FPS = 30 (main.rs:41); 735 samples: the FFT path
+    nf = pcm.size // hop
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_db = torch.empty((nf, n), device="cuda")
+    d_mask = torch.zeros((nf, (n + 31) // 32), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    d_c = torch.zeros((nf, 64), device="cuda")
+    d_s = torch.zeros((nf, 64), device="cuda")
+    v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt, d_c, d_s, 64)
+    torch.cuda.synchronize()
+    db, cnt, ctr, sz = d_db.cpu().numpy(), d_cnt.cpu().numpy(), d_c.cpu().numpy(), d_s.cpu().numpy()
+    assert cnt.max() >= 3 and (cnt > 0).sum() > nf // 2       # the stimulus really lights LEDs
+    exact = off_by_one = 0
+    for f in range(nf):
+        k = int(cnt[f])
+        got = P.led_frame(n, bpo, list(zip(ctr[f, :k].tolist(), sz[f, :k].tolist())))
+        _, wce, wsz = O.analyze_frame(db[f], op.min_freq, op.octaves, bpo)
+        want = OC.led_frame(n, bpo, list(zip(wce.tolist(), wsz.tolist())), PC.SERIAL_COLORS, PC.SERIAL_GRAY_LEVEL,
+                            PC.SERIAL_EASING_POW)
+        assert len(got) == len(want) == 3 + 3 * n and got[:3] == want[:3] and max(got[3:]) <= 0xFE
+        d = np.abs(np.frombuffer(got, np.uint8).astype(int) - np.frombuffer(want, np.uint8).astype(int))
+        assert d.max() <= 1, f
+        exact += int(d.max() == 0)
+        off_by_one += int(d.max() == 1)
+    assert exact >= int(0.97 * nf), (exact, off_by_one, nf)
+    # (b) the reference's stateful loop
+    st = P.AnalysisState.new(pp.range)
+    ost = OracleAnalysisState(op.min_freq, op.octaves, bpo)
+    same = 0
+    for f in range(nf):
+        st.preprocess(db[f], 1.0 / 30.0)
+        ost.preprocess(db[f], int(round(1e9 / 30.0)))
+        got = P.led_frame(n, bpo, [(p.center, p.size) for p in st.peaks_continuous])
+        want = OC.led_frame(n, bpo, list(zip(ost.centers.tolist(), ost.sizes.tolist())), PC.SERIAL_COLORS,
+                            PC.SERIAL_GRAY_LEVEL, PC.SERIAL_EASING_POW)
+        assert sorted(st.peaks) == list(ost.peaks), f
+        d = np.abs(np.frombuffer(got, np.uint8).astype(int) - np.frombuffer(want, np.uint8).astype(int))
+        # the two EMA evaluations differ by an ulp and the log-frequency parabola amplifies that to ~1e-2 bins
+        # (tests/test_analysis_state.py): the brightness split between the two buckets of a peak moves by a few levels
+        assert d.max() <= 6, (f, int(d.max()))
+        same += int(d.max() <= 1)
+    assert same >= int(0.9 * nf), (same, nf)
+    print(f"LED frames: stateless {exact}/{nf} identical, {off_by_one} one level apart; stateful {same}/{nf} within one level")

@@ -15,8 +15,9 @@ def _sweep_max_and_sum(ov, p, freqs):
 
 
 def test_vqt_bandwidths():
-    """vqt.rs:996-1027: no coverage holes across 588x20 log-spaced sines (every 4th point here keeps
-    the CPU suite short; the GPU suite runs the full sweep)."""
+    """vqt.rs:996-1027: no coverage holes across 588x20 log-spaced sines.  Every 4th point here keeps the CPU suite
+    short; tests/test_reference_properties_gpu.py::test_vqt_bandwidths_full_sweep runs all 11 740 points through the
+    HIP path (both algorithms) and through this oracle on the GPU box."""
     p = O.default_params()
     ov = O.OracleVqt(p)
     sub = 20

@@ -13,7 +13,7 @@ import pytest
 
 import oracle as O
 import pitchvis_amd as P
-from helpers import get_geom, white_noise, mask_to_indices
+from helpers import get_geom, white_noise, mask_to_indices, report
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -143,5 +143,6 @@ def test_end_to_end_peak_sets_with_near_threshold_accounting():
         # ... and end to end the sets agree unless a threshold is within the dB tolerance
         if not np.array_equal(gp, O.find_peaks_split(wdb[f], 36)):
             differing.append(f)
-    print(f"end-to-end peak sets differ in {len(differing)} of {nf} frames (near-threshold): {differing[:20]}")
+    report("parity_evidence_r02.txt", f"# tests/test_peaks_gpu.py end-to-end: peak sets differ in {len(differing)} of {nf} frames "
+                                      f"(near-threshold; each accounted for in test_parity_evidence_gpu.py): {differing[:20]}")
     assert len(differing) <= nf // 100

@@ -1,0 +1,193 @@
+"""The reference's own property tests, run through the HIP path (C ABI) at full density.
+
+These sweeps are the only anchors the reference itself holds for this path (it ships no golden
+vectors): `test_vqt_bandwidths` (vqt.rs:996-1027, 588 x 20 sines, threshold 3 dB),
+`test_vqt_group_boundary_continuity` (vqt.rs:1032-1076, 3 dB), `test_vqt_high_frequencies`
+(lib.rs:50-72, 6 dB), `test_vqt_close_frequencies` (lib.rs:16-48, exactly two peaks), plus the
+analytic on-centre known answers (26.287 dB at 22 050 Hz / 588 bins, 29.666 dB at 48 kHz / 252 bins).
+
+Every stimulus is one n_fft buffer of the reference (`test_create_sines`, util.rs:62-79).  A call of
+`calculate_vqt_instant_in_db` reads only the window union (the last 8 192 samples at the default
+geometry), so the stimuli are laid end to end as a stream of their last L = union samples and frame
+(i + 1) L / hop - 1 of the batch IS the reference's call on stimulus i: with hop = L the FFT path
+takes it, with hop = 256 the block-DFT path (the benchmark's kernels) does and the frames in between
+are simply not looked at.  Both algorithms run every sweep unsub-sampled; the CPU oracle runs the same
+stimuli next to them and the largest GPU - oracle difference is asserted and written to
+gpurun_out/reference_properties_r02.txt (copied to profiles/ by the builder).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+import pitchvis_amd as P
+from helpers import get_geom, report
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ALGOS = [P.ALGO_FFT, P.ALGO_BLOCKDFT]
+ALGO_NAME = {P.ALGO_FFT: "fft", P.ALGO_BLOCKDFT: "blockdft"}
+
+
+def _report(line):
+    report("reference_properties_r02.txt", line)
+
+
+def sines_tail(op, freq_sets, L):
+    """The last L samples of test_create_sines(params, freqs, 0.0) for every entry of freq_sets,
+    evaluated in f32 in the reference's order (util.rs:72-75): (((i * 2) * PI) / sr) * f, sin, / 12."""
+    i = np.arange(op.n_fft - L, op.n_fft, dtype=np.float32)
+    t = (i * np.float32(2.0)) * np.float32(np.pi) / np.float32(op.sr)
+    out = np.zeros((len(freq_sets), L), np.float32)
+    for k, fs in enumerate(freq_sets):
+        for f in fs:
+            out[k] += np.sin(t * np.float32(f)) / np.float32(12.0)
+    return out
+
+
+def run_stimuli(v, op, tails, algo):
+    """dB frames [n_stimuli][n_bins] of the reference's per-buffer calls, through the batch entry point."""
+    n, L = tails.shape
+    assert L % 256 == 0 and L >= v.window_union
+    hop = L if algo == P.ALGO_FFT else 256
+    per = L // hop
+    v.set_algo(algo)
+    v.set_gemm_precision(P.GEMM_F32)
+    out = np.empty((n, v.n_bins), np.float32)
+    step = 2048   # stimuli per call: bounds the device buffers (588 bins x 32 frames per stimulus at hop 256)
+    for s0 in range(0, n, step):
+        s1 = min(n, s0 + step)
+        d_pcm = torch.from_numpy(np.ascontiguousarray(tails[s0:s1]).reshape(-1)).cuda()
+        nf = (s1 - s0) * per
+        d_db = torch.empty((nf, v.n_bins), device="cuda")
+        v.calculate_batch_db_device(d_pcm, hop, nf, d_db)
+        torch.cuda.synchronize()
+        assert v.last_algo() == algo
+        out[s0:s1] = d_db[per - 1::per].cpu().numpy()
+    return out
+
+
+def oracle_stimuli(ov, op, tails):
+    n, L = tails.shape
+    return ov.calculate_batch(np.ascontiguousarray(tails).reshape(-1), L, n)
+
+
+def _union_len(v):
+    return (v.window_union + 255) // 256 * 256
+
+
+def test_stimulus_generator_matches_the_reference_formula():
+    _, op = get_geom("default_22k_588")
+    L = 8192
+    for f in (55.0, 441.3, 6999.0):
+        a = sines_tail(op, [[np.float32(f)]], L)[0]
+        b = O.test_create_sines(op, [np.float32(f)])[-L:]
+        assert np.abs(a - b).max() <= 2e-7   # numpy's and glibc's sinf differ by an ulp at most
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_vqt_bandwidths_full_sweep(algo):
+    """vqt.rs:996-1027, all 11 740 sines: max over the sweep of the strongest bin's dB minus the min over the
+    sweep of the frame's dB sum stays below 3 dB (no coverage holes between neighbouring bins)."""
+    pp, op = get_geom("default_22k_588")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    sub = 20
+    n = op.n_buckets()
+    idx = np.arange(sub // 2, n * sub - sub // 2)
+    assert idx.size == 588 * 20 - 20
+    freqs = np.float32(op.min_freq) * np.power(np.float32(2.0), idx.astype(np.float32) / np.float32(op.buckets_per_octave * sub))
+    tails = sines_tail(op, [[f] for f in freqs], _union_len(v))
+    db = run_stimuli(v, op, tails, algo)
+    mx = db.max(axis=1)
+    sm = np.array([row.sum(dtype=np.float32) for row in db])
+    wdb = oracle_stimuli(ov, op, tails)
+    wmx = wdb.max(axis=1)
+    _report(f"test_vqt_bandwidths [{ALGO_NAME[algo]}] {idx.size} sines: max_single {mx.max():.3f} dB, min_sum {sm.min():.3f} dB, "
+            f"margin {mx.max() - sm.min():.3f} < 3.0 | oracle {wmx.max():.3f} / {wdb.sum(axis=1, dtype=np.float32).min():.3f} | "
+            f"max |dB_gpu - dB_oracle| {np.abs(db - wdb).max():.2e}, on the strongest bin {np.abs(mx - wmx).max():.2e}")
+    assert mx.max() - sm.min() < 3.0
+    assert (db.argmax(axis=1) == wdb.argmax(axis=1)).all()
+    assert np.abs(mx - wmx).max() <= 2e-4
+    assert np.abs(db - wdb).max() <= 1e-2
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_vqt_group_boundary_continuity_full(algo):
+    """vqt.rs:1032-1076: +- a quarter semitone around every rate-group boundary in 41 steps: spread < 3 dB."""
+    pp, op = get_geom("default_22k_588")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    freq, _, M, _ = v.filter_params()
+    boundaries = [freq[i + 1] for i in range(len(M) - 1) if M[i] != M[i + 1]]
+    assert boundaries and boundaries == [ov.filter_params()[0][i + 1] for i in range(len(M) - 1) if M[i] != M[i + 1]]
+    steps = 20
+    sets = [[np.float32(b) * np.float32(2.0) ** np.float32(i / (steps * 4.0 * 12.0))] for b in boundaries for i in range(-steps, steps + 1)]
+    tails = sines_tail(op, sets, _union_len(v))
+    db = run_stimuli(v, op, tails, algo)
+    wdb = oracle_stimuli(ov, op, tails)
+    mx = db.max(axis=1).reshape(len(boundaries), 2 * steps + 1)
+    spread = mx.max(axis=1) - mx.min(axis=1)
+    _report(f"test_vqt_group_boundary_continuity [{ALGO_NAME[algo]}] {len(boundaries)} boundaries: spreads "
+            + " ".join(f"{b:.1f}Hz:{s:.2f}" for b, s in zip(boundaries, spread))
+            + f" (< 3.0) | max |dB_gpu - dB_oracle| on the strongest bin {np.abs(db.max(axis=1) - wdb.max(axis=1)).max():.2e}")
+    assert (spread < 3.0).all()
+    assert np.abs(db.max(axis=1) - wdb.max(axis=1)).max() <= 2e-4
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_vqt_high_frequencies_full(algo):
+    """lib.rs:50-72: single sines across the octaves: inf(max dB) > sup(max dB) - 6."""
+    pp, op = get_geom("default_22k_588")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    sub = 30
+    sets = [[np.float32(op.min_freq) * np.float32(2.0) ** (np.float32(i) + np.float32(j) / np.float32(12.0 * sub))]
+            for i in range(op.octaves) for j in range(sub)]
+    tails = sines_tail(op, sets, _union_len(v))
+    db = run_stimuli(v, op, tails, algo)
+    wdb = oracle_stimuli(ov, op, tails)
+    mx = db.max(axis=1)
+    _report(f"test_vqt_high_frequencies [{ALGO_NAME[algo]}] {len(sets)} sines: inf {mx.min():.3f}, sup {mx.max():.3f} (inf > sup - 6) | "
+            f"max |dB_gpu - dB_oracle| on the strongest bin {np.abs(mx - wdb.max(axis=1)).max():.2e}")
+    assert mx.min() > mx.max() - 6.0
+    assert np.abs(mx - wdb.max(axis=1)).max() <= 2e-4
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_vqt_close_frequencies_both_algorithms(algo):
+    """lib.rs:16-48 with the product's own AnalysisState (fresh state, 1100 ms step): exactly two peaks."""
+    pp, op = get_geom("default_22k_588")
+    v = P.Vqt.new(pp, 0)
+    sub = 30
+    sets = []
+    for i in range(int(2.6 * sub), op.octaves * sub - sub // 2):
+        ln = np.float32(i) / np.float32(sub)
+        sets.append([np.float32(op.min_freq) * np.float32(2.0) ** ln,
+                     np.float32(op.min_freq) * np.float32(2.0) ** (ln + np.float32(1.0 / 12.0))])
+    tails = sines_tail(op, sets, _union_len(v))
+    db = run_stimuli(v, op, tails, algo)
+    counts = []
+    for row in db:
+        st = P.AnalysisState.new(pp.range)
+        st.preprocess(row, 1.1)
+        counts.append(len(st.peaks))
+    _report(f"test_vqt_close_frequencies [{ALGO_NAME[algo]}] {len(sets)} pairs: peak counts {sorted(set(counts))}")
+    assert counts == [2] * len(sets)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("geom,bin_,expect", [("default_22k_588", 300, 26.287), ("bench_48k_252", 130, 29.666)])
+def test_on_centre_sine_kat_gpu(geom, bin_, expect, algo):
+    """|X_k| = sqrt(sr) a / 2 for an on-centre sine of amplitude a = 1/12 (vqt.rs:802-805, :646, :923)."""
+    pp, op = get_geom(geom)
+    v = P.Vqt.new(pp, 0)
+    f = v.filter_params()[0][bin_]
+    tails = sines_tail(op, [[f]], _union_len(v))
+    db = run_stimuli(v, op, tails, algo)[0]
+    analytic = 20 * np.log10(np.sqrt(op.sr) * (1 / 12) / 2) - 10 * np.log10(0.09)
+    _report(f"on-centre KAT [{geom}, {ALGO_NAME[algo]}]: bin {db.argmax()} {db.max():.4f} dB, analytic {analytic:.4f} dB")
+    assert abs(analytic - expect) < 1e-3
+    assert db.argmax() == bin_
+    assert abs(db.max() - analytic) < 0.01
+    assert (db[np.abs(np.arange(db.size) - bin_) > 40] == 0).all()

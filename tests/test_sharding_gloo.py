@@ -1,7 +1,11 @@
-"""Multi-rank path on CPU: world_size-2 (and 3) gloo processes each take a frame shard with its
-halo, compute it (the CPU oracle stands in for the GPU kernel here), and rank 0 checks the
-gathered result equals the unsharded computation bit for bit.  Exercises exactly the plumbing
-bench.py uses at N > 1 (plan_shard, barrier, max-over-ranks reduce)."""
+"""Multi-rank path on CPU: world_size-2 (and 3) gloo processes run the host-side plumbing bench.py uses at N > 1 —
+the product's own host plan (pitchvis_amd.Vqt without a device: window union, bin count), pitchvis_amd.sharding
+(plan_shard, global_stream with one seed on every rank, local_pcm with the real halo), the barrier and the
+max-over-ranks reduce — and rank 0 checks that the gathered shards equal the unsharded computation bit for bit.
+There is no GPU in this container and the product has no CPU fallback, so the frame transform itself is the CPU oracle
+standing in for the kernels; the same shard plumbing through the HIP kernels is checked on the GPU box by
+tests/test_configs_gpu.py::test_config3_sharded_equals_unsharded, ::test_config3_full_size_shard_on_one_gpu and
+::test_bench_two_ranks_gloo_on_one_gpu."""
 import os
 import socket
 
@@ -11,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pitchvis_amd.sharding import plan_shard
+from pitchvis_amd.sharding import global_stream, local_pcm, plan_shard
 
 
 def test_plan_shard_covers_everything():
@@ -34,13 +38,19 @@ def _worker(rank, world, port, hop, n_frames, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pitchvis_amd as P
     op = O.OracleParams(sr=22050.0, min_freq=55.0, octaves=5, buckets_per_octave=36, quality=1.8, gamma=4.8 * 1.8)
     ov = O.OracleVqt(op)
-    union = op.n_fft - min(ov.group_info(g)["window"][0] for g in range(ov.n_groups))
-    rng = np.random.default_rng(99)
-    pcm = (rng.random(hop * n_frames, dtype=np.float32) - 0.5).astype(np.float32)  # same stream on every rank
+    # the product's host plan (no device): the numbers bench.py shards with
+    v = P.Vqt(P.VqtParameters(sr=22050.0, range=P.VqtRange(55.0, 5, 36), quality=1.8, gamma=4.8 * 1.8), device=None)
+    union = v.window_union
+    assert union == op.n_fft - min(ov.group_info(g)["window"][0] for g in range(ov.n_groups)) and v.n_bins == ov.n_bins
+    stream = global_stream(0x5EED0003, hop * n_frames, "cpu")                       # same stream on every rank
     s = plan_shard(n_frames, hop, union, rank, world)
-    local = ov.calculate_batch(pcm[s.sample_begin:s.sample_end], hop, s.n_frames, n_lead=s.n_lead)
+    mine = local_pcm(stream, s).numpy()
+    pcm = stream.numpy()
+    assert mine.size == s.n_lead + s.n_frames * hop and np.array_equal(mine, pcm[s.sample_begin:s.sample_end])
+    local = ov.calculate_batch(mine, hop, s.n_frames, n_lead=s.n_lead)
     dist.barrier()
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduce of bench.py
