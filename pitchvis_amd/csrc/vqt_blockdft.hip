@@ -192,7 +192,7 @@ struct GemmTreeArgs {
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
-    unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader-clock ticks, 100 MHz ticks) of its K loop
+    unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader clock, 100 MHz clock) before and after its K loop
 };
 #define PVQ_STAMP(i) \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();
@@ -451,7 +451,7 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
 }
 
 template <int BM>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 complex columns
-__global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(GemmTreeArgs a) {
+__global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) {   // 4 waves per SIMD = two 512-thread (four 256-thread) workgroups per CU: at most 128 registers
     constexpr int B_FLOATS = FR_KC * FT_BN;
     constexpr int P_FLOATS = BM * FT_LDP * 2;
     __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice, then the P tile
@@ -476,20 +476,20 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree(
         acc0[q] = 0.0f;
         acc1[q] = 0.0f;
     }
-    // the clock the chip holds under this kernel's MFMA load: shader-clock ticks over 100 MHz ticks across the K loop
-    const bool clk_me = a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0;
-    unsigned long long clk_c = 0, clk_r = 0;
-    if (clk_me) {
-        clk_c = __builtin_amdgcn_s_memtime();
-        clk_r = __builtin_amdgcn_s_memrealtime();
+    // the clock the chip holds under this kernel's MFMA load: shader-clock ticks over 100 MHz ticks across the K loop.  The
+    // start stamps go straight to memory so that nothing stays live in registers across the loop (the kernel sits at the
+    // 128-register edge of four waves per SIMD).
+    if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
+        a.clk[(blockIdx.x >> 6) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
     if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
         fused_f32_kloop<true, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
     else
         fused_f32_kloop<false, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
-    if (clk_me) {
-        a.clk[(blockIdx.x >> 6) * 2 + 0] = __builtin_amdgcn_s_memtime() - clk_c;
-        a.clk[(blockIdx.x >> 6) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r;
+    if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
+        a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
+        a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
     PVQ_STAMP(1);
     __syncthreads();   // the E slice is dead: the P' tile takes its place
@@ -1348,12 +1348,12 @@ static inline float host_from_bf16(uint16_t h) {
 float Vqt::last_sclk_mhz() {
     if (!dev_ || !dev_->block || !dev_->block->d_clk || dev_->block->clk_n <= 0) return 0.0f;
     BlockDftTables* t = dev_->block;
-    std::vector<unsigned long long> h((size_t)t->clk_n * 2);
+    std::vector<unsigned long long> h((size_t)t->clk_n * 4);
     if (hipSetDevice(device_id_) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0.0f;
     if (hipMemcpy(h.data(), t->d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0.0f;
     std::vector<double> r;
     for (int i = 0; i < t->clk_n; ++i)
-        if (h[2 * i + 1] > 0) r.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+        if (h[4 * i + 3] > h[4 * i + 1]) r.push_back(100.0 * (double)(h[4 * i + 2] - h[4 * i]) / (double)(h[4 * i + 3] - h[4 * i + 1]));
     if (r.empty()) return 0.0f;
     std::sort(r.begin(), r.end());
     return (float)r[r.size() / 2];
@@ -1852,7 +1852,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             last_gemm_flop_ = (double)real_tiles * fused_bm * FT_BN * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
             fa.clk = nullptr;
             if (profiling_ && !use_bf) {
-                const size_t need = ((size_t)off / 64 + 1) * 2 * sizeof(unsigned long long);
+                const size_t need = ((size_t)off / 64 + 1) * 4 * sizeof(unsigned long long);
                 if (t->clk_cap < need) {
                     if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
                     t->d_clk = nullptr; t->clk_cap = 0;

@@ -1,0 +1,39 @@
+"""Occupancy guard for the hand-written kernels (no GPU needed: hipcc cross-compiles and reports register use).
+The fused GEMM + tree kernel runs two 512-thread workgroups per CU = four waves per SIMD, which holds only up to 128
+vector registers per lane; one register more silently halves its occupancy (measured: 0.36 -> 0.42 ms per launch)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_register_budgets_of_the_block_dft_kernels(tmp_path):
+    src = os.path.join(ROOT, "pitchvis_amd", "csrc", "vqt_blockdft.hip")
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
+                        "-c", src, "-o", str(tmp_path / "x.o")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    usage = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).split(" ")[0]] = int(m.group(2))
+
+    def find(sub):
+        hits = [v for k, v in usage.items() if sub in k]
+        assert hits, (sub, list(usage))
+        return hits
+
+    for u in find("blockdft_gemm_treeILi256") + find("blockdft_gemm_treeILi128") + find("blockdft_gemm_tree_bf16x3ILi256"):
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # two 512-thread workgroups per CU
+    for u in find("blockdft_banddots8_dbILi8ELi4ELi260"):
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # 8 waves x 2 workgroups per CU

@@ -6,9 +6,11 @@
    evaluation of sum_n x[n] g_k[n] can promise is an ABSOLUTE error proportional to the input it sums
    (eps * sqrt(sr) * max|x| * a modest growth factor), not a relative error per bin: a bin 60 dB down
    carries the same absolute error as the strongest one, so its relative error is 1000 x larger — on the
-   CPU path exactly as on the GPU.  The table shows that; the assertions are on the absolute error
-   (<= 2e-6 of the frame maximum at every level, five times inside north_star's 1e-5) and on the GPU
-   staying within 4 x the oracle's own error + 2e-7 in every level bin.
+   CPU path exactly as on the GPU.  The table shows that; the assertions are on the absolute error:
+   <= 4e-7 of the input scale sqrt(sr) max|x| for every bin of every frame (the universal bound; measured
+   2.3e-7 at worst, on coherent sweeps, where the CPU path itself reaches 1.9e-7), <= 1e-5 of the frame
+   maximum (north_star's figure) at every level for every frame whose maximum reaches 1 % of the input scale, <= 2e-6 for frames that reach 10 %, per-bin relative <= 1e-5 within 10 dB of
+   the maximum, and the GPU within 4 x the oracle's own error + 2e-7.
 2. Stream start: the first frames after silence see the signal only through the Hann tails, their
    coefficients are the residue of large cancelling terms, and errors relative to the (tiny) frame maximum
    reach 1e-3.  The table prints, per frame, the frame maximum and both errors against the input scale
@@ -90,17 +92,27 @@ def test_error_versus_level(geom, algo):
         inp = np.sqrt(op.sr) * xp                                  # what a full-scale sine of the window's peak amplitude would give
         fmax = np.abs(truth).max(axis=1)
         well = (fmax >= 0.01 * inp) & (fmax > 0)                   # frames whose output is not the residue of cancelling terms
+        live = xp > 0
+        # the universal bound: absolute error against the input scale, every bin of every frame
+        ei_g = (np.abs(cx - truth).max(axis=1)[live] / inp[live]).max()
+        ei_c = (np.abs(wcx - truth).max(axis=1)[live] / inp[live]).max()
+        report(OUT, f"{geom} {NAME[algo]} {case}: {int(live.sum())} frames, max abs err / (sqrt(sr) max|x|): gpu {ei_g:.2e}, oracle {ei_c:.2e}")
+        assert ei_g <= 4e-7 and ei_g <= 2.0 * ei_c + 1e-7, (geom, algo, case, ei_g, ei_c)   # measured: <= 2.3e-7 (coherent sweeps), the CPU path <= 1.9e-7
         if well.any():
             scale = fmax[well][:, None]
             rows = _level_table(f"{geom} {NAME[algo]} {case}", cx[well], wcx[well], truth[well], scale)
             for (lo, hi, n, rgm, rgmed, rcm, rcmed, agm, acm) in rows:
-                assert agm <= 2e-6, (geom, algo, case, lo, agm)        # absolute error in units of the frame maximum, at every level
-                if hi <= 20:                                           # bins within 20 dB of the maximum: the relative bar itself
+                assert agm <= 1e-5, (geom, algo, case, lo, agm)        # north_star's bar, in units of the frame maximum, at every level
+                if hi <= 10:                                           # the strongest bins: the bar as a per-bin relative error
                     assert rgm <= 1e-5, (geom, algo, case, lo, rgm)
             e_gpu = (np.abs(cx[well] - truth[well]) / scale).max()
             e_cpu = (np.abs(wcx[well] - truth[well]) / scale).max()
-            report(OUT, f"{geom} {NAME[algo]} {case}: {int(well.sum())} frames, max abs err / frame max: gpu {e_gpu:.2e}, oracle {e_cpu:.2e}")
+            full = well & (fmax >= 0.1 * inp)                          # frames that fill their windows (not dominated by cancellation)
+            e_full = (np.abs(cx[full] - truth[full]) / fmax[full][:, None]).max() if full.any() else 0.0
+            report(OUT, f"{geom} {NAME[algo]} {case}: {int(well.sum())} frames with max|z| >= 1 % of the input scale: max abs err / frame max: "
+                        f"gpu {e_gpu:.2e}, oracle {e_cpu:.2e}; {int(full.sum())} frames with max|z| >= 10 %: gpu {e_full:.2e}")
             assert e_gpu <= 4.0 * e_cpu + 2e-7, (geom, algo, case, e_gpu, e_cpu)
+            assert e_full <= 2e-6, (geom, algo, case, e_full)
         ill = (~well) & (xp > 0)
         if ill.any():
             # stream start (and any other cancellation-dominated frame): errors against the frame maximum and against the input scale
@@ -112,7 +124,7 @@ def test_error_versus_level(geom, algo):
                 if f < 40 or f % 16 == 0:
                     report(OUT, f"{geom} {NAME[algo]} {case} frame {f:4d}  {fmax[f] / inp[f]:.2e}  {eg / max(fmax[f], 1e-30):.2e}  "
                                 f"{ec / max(fmax[f], 1e-30):.2e}  {eg / inp[f]:.2e}  {ec / inp[f]:.2e}")
-                assert eg / inp[f] <= 1e-7, (geom, algo, case, f, eg / inp[f])   # = 1e-5 of the 1 % floor, the bar of test_parity_gpu.py
+                assert eg / inp[f] <= 1e-7, (geom, algo, case, f, eg / inp[f])   # = 1e-5 of the 1 % floor, the bar of test_parity_gpu.py (these frames see little of the signal)
 
 
 def _decisive_margin(frame, b, bpo, ap):
