@@ -35,8 +35,7 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
 
     std::vector<float2> split_tw;
     std::vector<uint32_t> row_ptr;
-    std::vector<float2> ent_val;
-    std::vector<uint16_t> ent_col;
+    std::vector<float4> ent;
     const double pi = 3.14159265358979323846;
 
     for (const WindowGroup& g : groups) {
@@ -57,7 +56,7 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
         d.n_rows = static_cast<int>(g.filter_bank.rows);
         d.first_bin = static_cast<int>(g.first_bin);
         d.row_ptr_off = static_cast<int>(row_ptr.size());
-        d.ent_off = static_cast<int>(ent_val.size());
+        d.ent_off = static_cast<int>(ent.size());
         d.split_off = static_cast<int>(split_tw.size());
         uint32_t max_col = 0;
         uint32_t rel = 0;
@@ -66,16 +65,14 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
         for (uint32_t r = 0; r < A.rows; ++r) {
             row_ptr.push_back(rel);
             for (uint32_t i = A.row_ptr[r]; i < A.row_ptr[r + 1]; ++i) {
-                ent_val.push_back(make_float2(A.values[i].re, A.values[i].im));
-                ent_col.push_back(static_cast<uint16_t>(A.col_idx[i]));
+                ent.push_back(make_float4(A.values[i].re, A.values[i].im, __builtin_bit_cast(float, static_cast<uint32_t>(A.col_idx[i])), 0.0f));
                 max_col = std::max(max_col, A.col_idx[i]);
                 ++rel;
             }
             if (B.nnz() > 0) {
                 // x_vqt += conj(Kneg . X)  ==  sum conj(Kneg) * conj(X)   (vqt.rs:896-910)
                 for (uint32_t i = B.row_ptr[r]; i < B.row_ptr[r + 1]; ++i) {
-                    ent_val.push_back(make_float2(B.values[i].re, -B.values[i].im));
-                    ent_col.push_back(static_cast<uint16_t>(B.col_idx[i] | 0x8000u));
+                    ent.push_back(make_float4(B.values[i].re, -B.values[i].im, __builtin_bit_cast(float, static_cast<uint32_t>(B.col_idx[i] | 0x8000u)), 0.0f));
                     max_col = std::max(max_col, B.col_idx[i]);
                     ++rel;
                 }
@@ -83,6 +80,8 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
         }
         row_ptr.push_back(rel);
         d.n_cols = static_cast<int>(max_col + 1);
+        d.tpr = 1;
+        while (d.tpr < 16 && d.tpr * 2 * std::max(d.n_rows, 1) <= 512) d.tpr *= 2;
         for (int c = 0; c < d.n_cols; ++c) {
             const double ang = -2.0 * pi * static_cast<double>(c) / static_cast<double>(ws);
             split_tw.push_back(make_float2(q(std::cos(ang)), q(std::sin(ang))));
@@ -91,7 +90,7 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
         t->max_cols = std::max(t->max_cols, d.n_cols);
         t->h_groups.push_back(d);
     }
-    t->total_entries = static_cast<int>(ent_val.size());
+    t->total_entries = static_cast<int>(ent.size());
 
     std::vector<float2> tw(static_cast<size_t>(t->n_tw));
     for (int m = 0; m < t->n_tw; ++m) {
@@ -104,8 +103,7 @@ DeviceTables* build_device_tables(const HostPlan& plan, bool twiddle_fp16, std::
     const std::vector<uint32_t> status(4, 0u);
 
     if (!upload(&t->d_status, status, msg) || !upload(&t->d_lnf, lnf, msg) || !upload(&t->d_groups, t->h_groups, msg) || !upload(&t->d_tw, tw, msg) || !upload(&t->d_split_tw, split_tw, msg) ||
-        !upload(&t->d_row_ptr, row_ptr, msg) || !upload(&t->d_ent_val, ent_val, msg) ||
-        !upload(&t->d_ent_col, ent_col, msg)) {
+        !upload(&t->d_row_ptr, row_ptr, msg) || !upload(&t->d_ent, ent, msg)) {
         free_device_tables(t);
         return nullptr;
     }
@@ -119,8 +117,7 @@ void free_device_tables(DeviceTables* t) {
     if (t->d_tw) (void)hipFree(t->d_tw);
     if (t->d_split_tw) (void)hipFree(t->d_split_tw);
     if (t->d_row_ptr) (void)hipFree(t->d_row_ptr);
-    if (t->d_ent_val) (void)hipFree(t->d_ent_val);
-    if (t->d_ent_col) (void)hipFree(t->d_ent_col);
+    if (t->d_ent) (void)hipFree(t->d_ent);
     if (t->d_lnf) (void)hipFree(t->d_lnf);
     if (t->d_status) (void)hipFree(t->d_status);
     delete t;

@@ -22,6 +22,7 @@ struct GroupDev {
     int row_ptr_off;  // into d_row_ptr (n_rows+1 entries, relative to ent_off)
     int ent_off;      // into d_ent_val / d_ent_col
     int split_off;    // into d_split_tw (n_cols entries: exp(-2 pi i c / window_size))
+    int tpr;          // lanes that share one kernel row in the FFT path's row dots: the largest power of two <= 512 / n_rows, at most 16
 };
 
 // block-DFT path tables (vqt_blockdft.hip), built lazily per hop
@@ -37,8 +38,9 @@ struct DeviceTables {
     float2* d_tw = nullptr;
     float2* d_split_tw = nullptr;
     uint32_t* d_row_ptr = nullptr;
-    float2* d_ent_val = nullptr;   // filter_bank values; negative_filter_bank values stored conjugated
-    uint16_t* d_ent_col = nullptr; // column | 0x8000 when the entry multiplies conj(X[col])
+    // one 16-byte record per kernel entry: (re, im, column | 0x8000 when the entry multiplies conj(X[col]) [as bits], 0);
+    // filter_bank values as they are, negative_filter_bank values stored conjugated
+    float4* d_ent = nullptr;
     float* d_lnf = nullptr;        // ln(f_k) per bin (host libm, peak_detection.rs:81-86)
     uint32_t* d_status = nullptr;  // [0]: sticky "a frame's spectrum was not finite" flag set by the dB stages (see Vqt::input_status)
     BlockDftTables* block = nullptr;

@@ -201,19 +201,21 @@ __device__ __forceinline__ float wave_min(float v) {
 // LDS; red: 2*(BLOCK/64) floats of LDS scratch.  Writes n_bins floats to out (global).
 // status: the handle's sticky flag word; bit 0 is raised when a coefficient of the frame is not finite (a NaN / Inf sample
 // in the frame's windows: the reference's callers drop such input, audio_desktop.rs:102-105, and peak_detection.rs:145
-// would panic on it)
-template <int BLOCK>
+// would panic on it).  T threads (T / 64 waves) share one frame; `red` holds that frame's 2 * T / 64 partial results; the
+// barrier is the workgroup's (every frame of a workgroup runs the epilogue at the same time); live = false: a padding
+// frame, nothing is stored.
+template <int T>
 __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_bins, float* __restrict__ out,
-                                            float* lds_out, int tid, unsigned* status) {
+                                            float* lds_out, int tid, unsigned* status, bool live = true) {
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
-    constexpr int NW = BLOCK / 64;
-    constexpr int PER = 4;  // supports n_bins <= 4*BLOCK
+    constexpr int NW = T / 64;
+    constexpr int PER = 1024 / T < 4 ? 4 : 1024 / T;  // supports n_bins <= 1024 (and <= 4 T)
     float d[PER];
     float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
     bool bad = false;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int k = tid + t * BLOCK;
+        const int k = tid + t * T;
         d[t] = 0.0f;
         if (k < n_bins) {
             const float2 z = xv[k];
@@ -226,7 +228,7 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
     }
     mx = wave_max(mx);
     mn = wave_min(mn);
-    if (status && __builtin_amdgcn_ballot_w64(bad) != 0 && (tid & 63) == 0) atomicOr(status, 1u);
+    if (status && live && __builtin_amdgcn_ballot_w64(bad) != 0 && (tid & 63) == 0) atomicOr(status, 1u);
     if ((tid & 63) == 0) {
         red[tid >> 6] = mx;
         red[NW + (tid >> 6)] = mn;
@@ -243,8 +245,8 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
     mn = fmaxf(mn, floor_db);
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int k = tid + t * BLOCK;
-        if (k < n_bins) {
+        const int k = tid + t * T;
+        if (k < n_bins && live) {
             const float c = fmaxf(d[t], floor_db);
             const float r = (mn > 0.0f) ? (c - mn) : fmaxf(c, 0.0f);
             out[k] = r;
@@ -271,84 +273,128 @@ struct FftArgs {
     const float2* tw;
     const float2* split_tw;
     const uint32_t* row_ptr;
-    const float2* ent_val;
-    const uint16_t* ent_col;
+    const float4* ent;   // (re, im, column | conj flag, -) per kernel entry
     float* out_db;
     float2* out_cplx;
     unsigned* status;
+    int dev_skip;   // developer knob PVQ_FFT_SKIP (timing experiments, wrong results): 1 skips the row dots, 2 the FFT passes
 };
 
-template <int BLOCK, int E>
-__global__ __launch_bounds__(BLOCK) void vqt_fft_frames(FftArgs a) {
+// T threads per frame, F = BLOCK / T frames per workgroup side by side: a 4096-sample window is a 2048-point complex FFT =
+// 128 radix-16 butterflies per pass, so a whole 512-thread workgroup on one frame leaves three quarters of its threads idle
+// through every pass (the trainer's geometry, pitchvis_train/src/train.rs:30-43: 13 M frames/s that way).  All frames of a
+// workgroup walk the same window groups in step, so the barriers inside the FFT passes stay the workgroup's.  The real split
+// writes the spectrum columns the kernel reads in place of the FFT output (column c and N - c come from the same pair of
+// FFT bins, so one thread computes both and nothing else touches that pair): no separate spectrum buffer, 19 KB of LDS per
+// frame at that geometry instead of 27, eight frames in flight per CU.
+template <int BLOCK, int E, int T>
+__global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // four waves per SIMD: two 512-thread workgroups per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* Z = reinterpret_cast<float2*>(smem);
-    float2* spec = Z + lpad(a.n_tw) + 1;
-    float2* xv = spec + a.max_cols;
-    float* red = reinterpret_cast<float*>(xv + a.n_bins);
-    const int tid = threadIdx.x;
+    constexpr int F = BLOCK / T;
+    const int tid = threadIdx.x, tl = tid % T, fl = tid / T;
+    const int zlen = lpad(a.n_tw) + 1;          // FFT buffer of the largest window, + the slot of its Nyquist column
+    const int per_frame = zlen + a.n_bins;      // complex slots per frame
+    float2* Z = reinterpret_cast<float2*>(smem) + (size_t)fl * per_frame;
+    float2* xv = Z + zlen;
+    float* red = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem) + (size_t)F * per_frame) + fl * 2 * (T / 64);
 
-    for (int frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
+    for (int fg = blockIdx.x; fg * F < a.n_frames; fg += gridDim.x) {
+        const bool live = fg * F + fl < a.n_frames;
+        const int frame = live ? fg * F + fl : a.n_frames - 1;   // a padding frame repeats the last one and stores nothing
         // x[j] of the reference's n_fft buffer is pcm[buf0 + j]; zeros before the stream start
         const long long buf0 = a.n_lead + (long long)(frame + 1) * a.hop - a.n_fft;
 
         for (int g = 0; g < a.n_groups; ++g) {
             const GroupDev G = a.groups[g];
             const int N = G.n_cplx;
-            // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]), as a flat float copy
+            // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]), as a flat float copy; eight loads in flight per thread
             {
                 float* Zf = reinterpret_cast<float*>(Z);
                 const long long s0 = buf0 + G.w0;
-                for (int i = tid; i < 2 * N; i += BLOCK) {
-                    const long long s = s0 + i;
-                    const float v = (s >= 0 && s < a.n_samples) ? a.pcm[s] : 0.0f;
-                    Zf[2 * lpad(i >> 1) + (i & 1)] = v;
-                }
-            }
-            __syncthreads();
-            lds_fft<BLOCK, E>(Z, N, a.tw, a.n_tw, tid);
-            // real split, only for the columns the kernel reads (c <= n_cols-1 <= N)
-            for (int c = tid; c < G.n_cols; c += BLOCK) {
-                const float2 za = Z[lpad(c & (N - 1))];
-                float2 zb = Z[lpad((N - c) & (N - 1))];
-                zb.y = -zb.y;
-                const float2 w = a.split_tw[G.split_off + c];
-                const float2 ev = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
-                const float2 dv = make_float2(0.5f * (za.x - zb.x), 0.5f * (za.y - zb.y));
-                const float2 t = cmul(w, dv);
-                spec[c] = make_float2(ev.x + t.y, ev.y - t.x);
-            }
-            __syncthreads();
-            // banded complex row dots: 16 lanes per row
-            {
-                const int sub = tid >> 4, l16 = tid & 15;
-                const uint32_t* rp = a.row_ptr + G.row_ptr_off;
-                for (int row = sub; row < G.n_rows; row += BLOCK / 16) {
-                    const int s = G.ent_off + rp[row], e = G.ent_off + rp[row + 1];
-                    float2 acc = make_float2(0.0f, 0.0f);
-                    for (int i = s + l16; i < e; i += 16) {
-                        const float2 v = a.ent_val[i];
-                        const uint32_t c = a.ent_col[i];
-                        float2 x = spec[c & 0x7fffu];
-                        if (c & 0x8000u) x.y = -x.y;
-                        acc.x += v.x * x.x - v.y * x.y;
-                        acc.y += v.x * x.y + v.y * x.x;
+                for (int i0 = tl; i0 < 2 * N; i0 += 8 * T) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * T;
+                        const long long sx = s0 + i;
+                        v[u] = (i < 2 * N && sx >= 0 && sx < a.n_samples) ? a.pcm[sx] : 0.0f;
                     }
 #pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) {
-                        acc.x += __shfl_xor(acc.x, o);
-                        acc.y += __shfl_xor(acc.y, o);
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * T;
+                        if (i < 2 * N) Zf[2 * lpad(i >> 1) + (i & 1)] = v[u];
                     }
-                    if (l16 == 0) xv[G.first_bin + row] = acc;
                 }
             }
-            // no barrier needed here: the next group's gather only writes Z (spec/xv untouched)
-            // and its FFT passes synchronise before spec is rewritten.
+            __syncthreads();
+            if (!(a.dev_skip & 2)) lds_fft<T, E>(Z, N, a.tw, a.n_tw, tl);
+            // real split, in place, only for the columns the kernel reads (c <= n_cols - 1 <= N): columns c and d = N - c
+            // are both made of FFT bins c and N - c
+            for (int c = tl; c <= N / 2; c += T) {
+                const int d = N - c;
+                const bool need_c = c < G.n_cols, need_d = d < G.n_cols && d != c;
+                if (!need_c && !need_d) continue;
+                const float2 zc = Z[lpad(c & (N - 1))], zd = Z[lpad(d & (N - 1))];
+                auto column = [&](float2 za, float2 zb, int col) {   // za = Z[col], zb = conj(Z[N - col])
+                    zb.y = -zb.y;
+                    const float2 w = a.split_tw[G.split_off + col];
+                    const float2 ev = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
+                    const float2 dv = make_float2(0.5f * (za.x - zb.x), 0.5f * (za.y - zb.y));
+                    const float2 t = cmul(w, dv);
+                    return make_float2(ev.x + t.y, ev.y - t.x);
+                };
+                float2 sc = make_float2(0.0f, 0.0f), sd = sc;
+                if (need_c) sc = column(zc, zd, c);
+                if (need_d) sd = column(zd, zc, d);
+                if (need_c) Z[lpad(c)] = sc;
+                if (need_d) Z[lpad(d)] = sd;   // d = N (the Nyquist column, from FFT bin 0) lands in the slot behind the buffer
+            }
+            __syncthreads();
+            // banded complex row dots (vqt.rs:889-910), the whole workgroup over all its frames: a team of G.tpr lanes
+            // walks one kernel row, every entry is fetched once (one 16-byte load) and applied to the F frames' spectra
+            {
+                const int tpr = G.tpr;
+                const int team = tid / tpr, tm = tid & (tpr - 1), n_teams = BLOCK / tpr;
+                const uint32_t* rp = a.row_ptr + G.row_ptr_off;
+                const float2* Z0 = reinterpret_cast<const float2*>(smem);
+                float2* xv0 = reinterpret_cast<float2*>(smem) + zlen;
+                for (int row = team; row < G.n_rows && !(a.dev_skip & 1); row += n_teams) {
+                    const int s = G.ent_off + rp[row], e = G.ent_off + rp[row + 1];
+                    float2 acc[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) acc[f] = make_float2(0.0f, 0.0f);
+                    for (int i = s + tm; i < e; i += tpr) {
+                        const float4 en = a.ent[i];
+                        const uint32_t c = __builtin_bit_cast(uint32_t, en.z);
+                        const int idx = lpad(c & 0x7fffu);
+                        const float sg = (c & 0x8000u) ? -1.0f : 1.0f;
+#pragma unroll
+                        for (int f = 0; f < F; ++f) {
+                            float2 x = Z0[(size_t)f * per_frame + idx];
+                            x.y *= sg;
+                            acc[f].x += en.x * x.x - en.y * x.y;
+                            acc[f].y += en.x * x.y + en.y * x.x;
+                        }
+                    }
+                    for (int o = tpr >> 1; o > 0; o >>= 1) {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) {
+                            acc[f].x += __shfl_xor(acc[f].x, o);
+                            acc[f].y += __shfl_xor(acc[f].y, o);
+                        }
+                    }
+                    if (tm == 0) {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) xv0[(size_t)f * per_frame + G.first_bin + row] = acc[f];
+                    }
+                }
+            }
+            __syncthreads();   // the next group's gather overwrites the spectrum columns
         }
-        __syncthreads();
-        if (a.out_cplx) {
-            for (int k = tid; k < a.n_bins; k += BLOCK) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
+        if (a.out_cplx && live) {
+            for (int k = tl; k < a.n_bins; k += T) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
         }
-        db_epilogue<BLOCK>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, nullptr, tid, a.status);
+        db_epilogue<T>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, nullptr, tl, a.status, live);
         __syncthreads();
     }
 }
@@ -611,25 +657,30 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     a.tw = dev_->d_tw;
     a.split_tw = dev_->d_split_tw;
     a.row_ptr = dev_->d_row_ptr;
-    a.ent_val = dev_->d_ent_val;
-    a.ent_col = dev_->d_ent_col;
+    a.ent = dev_->d_ent;
     a.out_db = d_out_db;
     a.out_cplx = reinterpret_cast<float2*>(d_out_cplx);
     a.status = dev_->d_status;
+    static const int skip_env = getenv("PVQ_FFT_SKIP") ? atoi(getenv("PVQ_FFT_SKIP")) : 0;
+    a.dev_skip = skip_env;
 
-    const size_t lds = sizeof(float2) * ((size_t)(dev_->n_tw + (dev_->n_tw >> 4)) + 1 + dev_->max_cols + a.n_bins) +
-                       sizeof(float) * 32;
-    const int grid = (int)std::min<size_t>(n_frames, 1u << 20);
+    // threads per frame: one radix-16 butterfly per thread and pass for the largest window; 512-thread workgroups hold
+    // 512 / T frames side by side (a single frame, e.g. the streaming front end's, keeps the whole workgroup)
+    const int n_tw = dev_->n_tw;
+    const int T = n_frames < 4 ? (n_tw <= 8192 ? 512 : 1024) : n_tw <= 2048 ? 128 : n_tw <= 4096 ? 256 : n_tw <= 8192 ? 512 : 1024;
+    const int BLOCK = T == 1024 ? 1024 : 512;
+    const int F = BLOCK / T;
+    const size_t lds = (size_t)F * (sizeof(float2) * ((size_t)(n_tw + (n_tw >> 4)) + 1 + a.n_bins) + sizeof(float) * 2 * (T / 64));
+    const int grid = (int)std::min<size_t>((n_frames + F - 1) / F, 1u << 20);
     slot_begin(SLOT_FFT_FRAMES, stream);
-    if (dev_->n_tw <= 512 * 16) {
-        auto kern = vqt_fft_frames<512, 16>;
+    auto launch = [&](auto kern) -> pvq_status {
         PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
-    } else {
-        auto kern = vqt_fft_frames<1024, 16>;
-        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, a);
-    }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, a);
+        return PVQ_OK;
+    };
+    pvq_status lst = T == 128 ? launch(vqt_fft_frames<512, 16, 128>) : T == 256 ? launch(vqt_fft_frames<512, 16, 256>)
+                     : T == 512 ? launch(vqt_fft_frames<512, 16, 512>) : launch(vqt_fft_frames<1024, 16, 1024>);
+    if (lst != PVQ_OK) return lst;
     slot_end(SLOT_FFT_FRAMES, stream);
     if (pk) {  // peak / note detection as its own launch (one wavefront per frame)
         slot_begin(SLOT_PEAKS, stream);
