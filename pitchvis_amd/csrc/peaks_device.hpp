@@ -114,8 +114,9 @@ __device__ __forceinline__ int pk_side_window(const float* x, int i, int n, int 
     return (ml & first) ? 1 : 2;
 }
 
-// enhance + promote for one peak (see refine note in vqt_engine.hip)
-__device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
+// enhance_peaks_continuous for one peak (peak_detection.rs:61-148): log-frequency parabola through the peak and its
+// neighbours, centre clamped between them, size interpolated at the centre
+__device__ __forceinline__ void pk_enhance(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
 #pragma clang fp contract(off)
     const int nb = a.n_bins;
     const float bpo = (float)a.bpo;
@@ -143,31 +144,42 @@ __device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParam
             sz = fmaxf(x[lower] * (1.0f - fract) + x[upper] * fract, 0.0f);
         }
     }
-    if (!(ctr > (float)a.highest_bassnote)) {
-        const float f0 = a.min_freq * exp2f(ctr / bpo);            // 2^(c/bpo)
-        const float p0 = exp2f((sz / 10.0f) * 3.32192809488736f);  // 10^(dB/10)
-        float score = 0.0f;
-        const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
+}
+
+// promote_bass_peaks_with_harmonics for one peak whose centre is not above highest_bassnote (peak_detection.rs:172-241)
+__device__ __forceinline__ void pk_promote(const float* x, const PeakParamsDev& a, float ctr, float& sz) {
+#pragma clang fp contract(off)
+    const int nb = a.n_bins;
+    const float bpo = (float)a.bpo;
+    const float f0 = a.min_freq * exp2f(ctr / bpo);            // 2^(c/bpo)
+    const float p0 = exp2f((sz / 10.0f) * 3.32192809488736f);  // 10^(dB/10)
+    float score = 0.0f;
+    const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
 #pragma unroll
-        for (int h = 2; h <= 5; ++h) {
-            const float hf = f0 * (float)h;
-            if (hf >= a.min_freq) {
-                const float hb = (log2f(hf) - log2f(a.min_freq)) * bpo;
-                if (hb >= 0.0f && hb < (float)nb) {
-                    const int lo = (int)floorf(hb);
-                    const int hi = min((int)ceilf(hb), nb - 1);
-                    const float frac = hb - truncf(hb);
-                    const float adb = (lo == hi) ? x[lo] : (x[lo] * (1.0f - frac) + x[hi] * frac);
-                    const float hp = exp2f((adb / 10.0f) * 3.32192809488736f);
-                    if (hp > p0 * a.harmonic_threshold) score += hp * wts[h - 2];
-                }
+    for (int h = 2; h <= 5; ++h) {
+        const float hf = f0 * (float)h;
+        if (hf >= a.min_freq) {
+            const float hb = (log2f(hf) - log2f(a.min_freq)) * bpo;
+            if (hb >= 0.0f && hb < (float)nb) {
+                const int lo = (int)floorf(hb);
+                const int hi = min((int)ceilf(hb), nb - 1);
+                const float frac = hb - truncf(hb);
+                const float adb = (lo == hi) ? x[lo] : (x[lo] * (1.0f - frac) + x[hi] * frac);
+                const float hp = exp2f((adb / 10.0f) * 3.32192809488736f);
+                if (hp > p0 * a.harmonic_threshold) score += hp * wts[h - 2];
             }
         }
-        if (score > 0.0f) {
-            const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
-            sz += 10.0f * log10f(boost);
-        }
     }
+    if (score > 0.0f) {
+        const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
+        sz += 10.0f * log10f(boost);
+    }
+}
+
+// enhance + promote for one peak
+__device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParamsDev& a, float& ctr, float& sz) {
+    pk_enhance(x, p, a, ctr, sz);
+    if (!(ctr > (float)a.highest_bassnote)) pk_promote(x, a, ctr, sz);
 }
 
 // scipy-style greedy distance suppression among the candidates with x >= min_height (only for dist > 1, e.g. 84 bins per
@@ -350,23 +362,24 @@ __device__ __forceinline__ bool pk_is_top(const float* x, int i, float xv) {
     return (x[i + 1] < xv) && ((l < xv) || (l == xv && x[i - 2] < xv));
 }
 
-// LDS scratch of the lean routine besides the frame: candidate list (u16), peak list (u16), peak flags (u8)
+// LDS scratch of the lean routine besides the frame and its peak list: candidate list (u16), peak flags (u8)
 __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return 3 * n + (dist > 1 ? 3 * n /*local maxima, kept at the bass / general height*/ : 0);
+    return 2 * n + (dist > 1 ? 3 * n /*local maxima, kept at the bass / general height*/ : 0);
 }
 
+// plist: where the frame's peak bins go (ascending, room for n / 2 + 1 u16); n_peaks receives their number.  The
+// continuous outputs are NOT produced here: the caller refines the peaks of several frames side by side (full lanes).
 template <int NK, bool DISTANCE>   // DISTANCE: min_distance > 1 (84 bins per octave)
-__device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
-                                                int lane) {
+__device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, uint16_t* plist, uint32_t& n_peaks, size_t frame,
+                                                const PeakParamsDev& a, int lane) {
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
     const int words = (n + 31) / 32;
     const float INF = __builtin_huge_valf();
     uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
-    uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);   // peaks, ascending
-    uint8_t* flag = scratch + 2 * npad;                              // flag[bin] = 1 for a peak
-    uint8_t* lmax = scratch + 3 * npad;                              // dist > 1 only: strict local maxima,
+    uint8_t* flag = scratch + npad;                                  // flag[bin] = 1 for a peak
+    uint8_t* lmax = scratch + 2 * npad;                              // dist > 1 only: strict local maxima,
     uint8_t* keep0 = lmax + npad;                                    //   survivors of the distance rule at the bass height,
     uint8_t* keep1 = keep0 + npad;                                   //   and at the general height
     float v[NK];
@@ -384,6 +397,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         if (i < npad) flag[i] = 0;
         if (DISTANCE && i < npad) lmax[i] = (i >= 1 && i < n - 1 && pk_is_top(x, i, v[k])) ? 1 : 0;
     }
+    n_peaks = 0;
     if (__ballot(plateau)) return false;
     if (DISTANCE) {   // find_peaks' distance rule runs before its prominence test, once per height threshold
         pk_distance_wave(x, n, lmax, a.bass_min_height, a.dist, keep0, clist, lane);   // clist is free until step 1
@@ -471,15 +485,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         }
     }
     if (a.count && lane == 0) a.count[frame] = total;
-    if (a.center) {
-        const uint32_t lim = total < a.max_peaks ? total : a.max_peaks;
-        for (uint32_t sidx = lane; sidx < lim; sidx += 64) {
-            float ctr, sz;
-            pk_refine(x, (int)plist[sidx], a, ctr, sz);
-            a.center[frame * a.max_peaks + sidx] = ctr;
-            a.size[frame * a.max_peaks + sidx] = sz;
-        }
-    }
+    n_peaks = total;
     return true;
 }
 

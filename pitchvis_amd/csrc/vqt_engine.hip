@@ -405,30 +405,131 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
 // ------------------------------------------------------------------------------------------------
 constexpr int PK_WAVES = 4;
 
-// Common case (min_distance <= 1 and no plateau peak in the frame): the lean routine.  A frame it
-// cannot take is flagged for peaks_frames_generic, which is launched right behind it.
-template <int NK, bool DISTANCE>
+// Common case (no plateau peak of three or more samples in the frame): the lean routine.  A frame it cannot take is
+// flagged for peaks_frames_generic, which is launched right behind it.
+// A workgroup (4 waves) takes PK_FPW frames per wave and pass: each wave finds the peaks of its frames (peak lists in LDS),
+// then the continuous outputs of all 4 x PK_FPW frames are refined side by side, one lane per peak over the pooled list:
+// a frame has ~17 peaks, so refining per frame left three quarters of the lanes idle through ~400 vector instructions;
+// pooled, enhance_peaks_continuous runs on full waves and promote_bass_peaks_with_harmonics (only the few peaks at or
+// below highest_bassnote need it, but any one of them made the whole wave walk through it) runs once over the pooled
+// bass peaks.
+// PK_FPW frames per wave and pass: 2 up to 384 bins; 1 beyond, where a second frame per wave would cost more occupancy
+// (LDS) than the denser refinement gives back
+// bass peaks one frame can hold: their centre is at most highest_bassnote, so their bin at most highest_bassnote + 1,
+// and peaks are never adjacent
+__host__ __device__ inline int peaks_bass_cap(int n_bins, int highest_bassnote) {
+    const int npad = (n_bins + 63) / 64 * 64;
+    const int by_bins = (highest_bassnote < n_bins ? highest_bassnote : n_bins) / 2 + 3;
+    return by_bins < npad / 2 ? by_bins : npad / 2;
+}
+__host__ __device__ inline size_t peaks_lean_lds_bytes(int n_bins, int dist, int PK_FPW, int highest_bassnote) {
+    const size_t PK_FPG = (size_t)PK_WAVES * PK_FPW;
+    const size_t npad = (size_t)((n_bins + 63) / 64 * 64);
+    return PK_FPG * sizeof(float) * (npad + 2 * PK_PAD)          // frames, +INF sentinels on both sides
+           + PK_WAVES * peaks_lean_scratch_bytes(n_bins, dist)   // per-wave scratch of the peak search
+           + 2 * PK_FPG * npad                                   // peak lists: npad / 2 u16 per frame
+           + ((2 * PK_FPG * (size_t)peaks_bass_cap(n_bins, highest_bassnote) + 3) & ~(size_t)3)   // pooled bass list: u16 (frame << 10 | slot)
+           + 2 * PK_FPG * sizeof(uint32_t) + 16;                 // per-frame peak counts, bass counter
+}
+
+template <int NK, bool DISTANCE, int PK_FPW>
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(NK <= 8 ? 7 : 4, 8))) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
                                                                        uint8_t* __restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int PK_FPG = PK_WAVES * PK_FPW;     // frames per workgroup and pass
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
-    const size_t per_wave = sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(n, a.dist);
-    float* xs = reinterpret_cast<float*>(pk_smem + wv * per_wave);
-    float* x = xs + PK_PAD;  // x[-PK_PAD..-1] and x[n..npad+PK_PAD-1] hold +INF sentinels
-    unsigned char* scratch = reinterpret_cast<unsigned char*>(xs + npad + 2 * PK_PAD);
-    for (int i = lane; i < PK_PAD; i += 64) xs[i] = __builtin_huge_valf();
-    for (int i = n + lane; i < npad + PK_PAD; i += 64) x[i] = __builtin_huge_valf();
-    for (int frame = blockIdx.x * PK_WAVES + wv; frame < n_frames; frame += gridDim.x * PK_WAVES) {
-        const float* src = db + (size_t)frame * n;
-        for (int i = lane; i < n; i += 64) x[i] = src[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const bool done = peaks_wave_lean<NK, DISTANCE>(x, scratch, (size_t)frame, a, lane);
-        if (lane == 0) redo[frame] = done ? 0 : 1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    const int row = npad + 2 * PK_PAD;
+    float* rows = reinterpret_cast<float*>(pk_smem);                                   // [PK_FPG][row]
+    unsigned char* scratch = pk_smem + PK_FPG * sizeof(float) * row + wv * peaks_lean_scratch_bytes(n, a.dist);
+    uint16_t* plists = reinterpret_cast<uint16_t*>(pk_smem + PK_FPG * sizeof(float) * row + PK_WAVES * peaks_lean_scratch_bytes(n, a.dist));
+    const int pl_cap = npad / 2;                                                       // peaks are never adjacent
+    uint16_t* bass = plists + PK_FPG * pl_cap;                                         // [PK_FPG * bass_cap]
+    const int bass_cap = peaks_bass_cap(n, a.highest_bassnote);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(pk_smem + ((reinterpret_cast<unsigned char*>(bass + PK_FPG * bass_cap) - pk_smem + 3) & ~(size_t)3));   // [PK_FPG]
+    uint32_t* n_bass = counts + PK_FPG;
+    // sentinels of this wave's rows
+    for (int g = 0; g < PK_FPW; ++g) {
+        float* xs = rows + (wv * PK_FPW + g) * row;
+        for (int i = lane; i < PK_PAD; i += 64) xs[i] = __builtin_huge_valf();
+        for (int i = n + lane; i < npad + PK_PAD; i += 64) xs[PK_PAD + i] = __builtin_huge_valf();
+    }
+    for (int base = blockIdx.x * PK_FPG; base < n_frames; base += gridDim.x * PK_FPG) {
+        if (tid == 0) *n_bass = 0;
+        // 1. peak search: each wave its PK_FPW frames
+        for (int g = 0; g < PK_FPW; ++g) {
+            const int fi = wv * PK_FPW + g;
+            const int frame = base + fi;
+            uint32_t np = 0;
+            if (frame < n_frames) {
+                float* x = rows + fi * row + PK_PAD;
+                const float* src = db + (size_t)frame * n;
+                for (int i = lane; i < n; i += 64) x[i] = src[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool done = peaks_wave_lean<NK, DISTANCE>(x, scratch, plists + fi * pl_cap, np, (size_t)frame, a, lane);
+                if (lane == 0) redo[frame] = done ? 0 : 1;
+                if (!done) np = 0;   // the generic kernel produces this frame's outputs, the continuous ones included
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) counts[fi] = np < a.max_peaks ? np : a.max_peaks;
+        }
+        if (!a.center) continue;   // uniform: mask / count only
+        __syncthreads();
+        // 2. enhance_peaks_continuous over the pooled peaks, one lane each; bass peaks are handed to step 3
+        uint32_t pre[PK_FPG + 1];
+        pre[0] = 0;
+#pragma unroll
+        for (int f = 0; f < PK_FPG; ++f) pre[f + 1] = pre[f] + counts[f];
+        const uint32_t total = pre[PK_FPG];
+        for (uint32_t p0 = 0; p0 < total; p0 += 256) {
+            const uint32_t p = p0 + tid;
+            if (p0 + (wv << 6) >= total) break;   // nothing for this wave
+            bool is_bass = false;
+            int fi = 0;
+            uint32_t slot = 0;
+            if (p < total) {
+#pragma unroll
+                for (int f = 1; f < PK_FPG; ++f) fi += (p >= pre[f]) ? 1 : 0;
+            }
+            uint32_t start = 0;
+#pragma unroll
+            for (int f = 0; f < PK_FPG; ++f) start = (fi == f) ? pre[f] : start;
+            slot = p - start;
+            if (p < total) {
+                const float* x = rows + fi * row + PK_PAD;
+                float ctr, sz;
+                pk_enhance(x, (int)plists[fi * pl_cap + slot], a, ctr, sz);
+                const size_t o = (size_t)(base + fi) * a.max_peaks + slot;
+                a.center[o] = ctr;
+                is_bass = !(ctr > (float)a.highest_bassnote);
+                if (!is_bass) a.size[o] = sz;
+            }
+            const unsigned long long bm = __ballot(is_bass);
+            if (bm) {
+                uint32_t off = 0;
+                if (lane == 0) off = atomicAdd(n_bass, (uint32_t)__popcll(bm));
+                off = __builtin_amdgcn_readfirstlane(off);
+                const uint32_t at = off + __popcll(bm & ((1ull << lane) - 1ull));
+                if (is_bass && at < (uint32_t)(PK_FPG * bass_cap)) bass[at] = (uint16_t)((fi << 10) | slot);
+            }
+        }
+        __syncthreads();
+        // 3. promote_bass_peaks_with_harmonics over the pooled bass peaks (the centre is recomputed: cheaper than carrying it)
+        const uint32_t nb_ = min(*n_bass, (uint32_t)(PK_FPG * bass_cap));
+        for (uint32_t q = tid; q < nb_; q += 256) {
+            const uint32_t e = bass[q];
+            const int fi = (int)(e >> 10);
+            const uint32_t slot = e & 1023u;
+            const float* x = rows + fi * row + PK_PAD;
+            float ctr, sz;
+            pk_enhance(x, (int)plists[fi * pl_cap + slot], a, ctr, sz);
+            pk_promote(x, a, ctr, sz);
+            a.size[(size_t)(base + fi) * a.max_peaks + slot] = sz;
+        }
+        __syncthreads();   // the rows, lists and counters are reused by the next pass
     }
 }
 
@@ -832,7 +933,6 @@ pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* o
 
 pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& a, hipStream_t stream) {
     const int npad = (a.n_bins + 63) / 64 * 64;
-    const int grid = (int)std::min<size_t>((n_frames + PK_WAVES - 1) / PK_WAVES, 1u << 20);
     const size_t lds_gen = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
     // bins per lane: 4 (<= 256 bins), 8 (<= 512), 12 (<= 768) or 16 (<= 1024); the lean kernel also has 6 (<= 384)
     auto launch_generic = [&](int g, const uint8_t* flags) {
@@ -849,11 +949,13 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
     if (st != PVQ_OK) return st;
     uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
     const int sweep_grid = (int)std::min<size_t>(256, (n_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES));
-    const size_t lds_lean = PK_WAVES * (sizeof(float) * (npad + 2 * PK_PAD) + peaks_lean_scratch_bytes(a.n_bins, a.dist));
+    const int fpw = a.n_bins <= 384 ? 2 : 1;
+    const size_t lds_lean = peaks_lean_lds_bytes(a.n_bins, a.dist, fpw, a.highest_bassnote);
+    const int grid_lean = (int)std::min<size_t>((n_frames + PK_WAVES * fpw - 1) / (PK_WAVES * fpw), 1u << 20);
     auto launch_lean = [&](auto nk_c, auto dist_c) {
         constexpr int NK = decltype(nk_c)::value;
         constexpr bool D = decltype(dist_c)::value;
-        hipLaunchKernelGGL((peaks_frames_lean<NK, D>), dim3(grid), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+        hipLaunchKernelGGL((peaks_frames_lean<NK, D, (NK <= 6 ? 2 : 1)>), dim3(grid_lean), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
     };
     using std::integral_constant;
     if (a.dist > 1) {
