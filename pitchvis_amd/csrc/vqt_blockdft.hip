@@ -114,6 +114,20 @@ struct BlockDftTables {
     } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
     int tile_list_next = 0;
     unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch
+    // one-kernel form (vqt_fused2.hpp): E in 16x16x4 B-operand order, per (column tile, wave) kernel-product segments and their
+    // coefficients, the unit list of the last launch size, the power rows
+    bool f2_ok = false;
+    float4* d_E16 = nullptr;
+    int4* d_f2_segs = nullptr;
+    float2* d_f2_B = nullptr;
+    std::vector<int4> h_f2_segs;
+    struct UnitList {
+        int4* d = nullptr; size_t cap = 0;
+        int nf = -1, blocks = 0;
+        double gemm_mfma = 0.0, dots_mfma = 0.0;   // matrix instructions of one launch
+    } f2_units[2];
+    int f2_units_next = 0;
+    float* d_pw = nullptr; size_t pw_cap = 0;
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -137,6 +151,12 @@ void free_blockdft_tables(BlockDftTables* t) {
     for (auto& tl : t->tile_lists)
         if (tl.d) (void)hipFree(tl.d);
     if (t->d_clk) (void)hipFree(t->d_clk);
+    if (t->d_E16) (void)hipFree(t->d_E16);
+    if (t->d_f2_segs) (void)hipFree(t->d_f2_segs);
+    if (t->d_f2_B) (void)hipFree(t->d_f2_B);
+    for (auto& ul : t->f2_units)
+        if (ul.d) (void)hipFree(ul.d);
+    if (t->d_pw) (void)hipFree(t->d_pw);
     delete t;
 }
 
@@ -1327,6 +1347,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
     }
 }
 
+}  // namespace pvq
+#include "vqt_fused2.hpp"
+namespace pvq {
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1672,11 +1696,113 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     std::vector<long long> tile_s(tile, 0);
     for (size_t g = 0; g < groups.size(); ++g)
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
+    // ---- one-kernel form (vqt_fused2.hpp): hop 256, windows of at most 64 blocks
+    std::vector<float4> E16;
+    std::vector<int4> f2_segs((size_t)tile * 8, make_int4(0, 0, 0, 0));
+    std::vector<float2> f2_B;
+    t->f2_ok = hop == 256 && t->nb_max <= 64;
+    if (t->f2_ok) {
+        const size_t K2 = hop / 2;
+        E16.resize((size_t)tile * K2 * 16);
+        for (int tt = 0; tt < tile; ++tt)
+            for (size_t m = 0; m < K2; ++m)
+                for (int n = 0; n < 16; ++n) {
+                    const float* e = E.data() + m * ntot + (size_t)tt * GM_BN;
+                    E16[((size_t)tt * K2 + m) * 16 + n] = make_float4(e[2 * n], e[2 * (n + 16)], e[2 * n + 1], e[2 * (n + 16) + 1]);
+                }
+        // Kernel-product blocks of 8 bins -> waves: a block is open from the column tile of its first column to that of its
+        // last; a wave holds one block's sums at a time, so blocks whose tile spans overlap need different waves (interval
+        // colouring: possible with 8 waves iff no tile has more than 8 open blocks).  Among the free waves the one with the
+        // least matrix work so far takes the block; waves w and w + 4 share a SIMD, so ties go 0, 1, 2, 3, 4, ...
+        for (size_t g = 0; g < groups.size() && t->f2_ok; ++g) {
+            const CsrMatrix& A = groups[g].filter_bank;
+            const CsrMatrix& Bm = groups[g].negative_filter_bank;
+            const BlockGroup& BG = t->groups[g];
+            int busy_until[8];
+            long long work[8];
+            for (int w = 0; w < 8; ++w) {
+                busy_until[w] = -1;
+                work[w] = 0;
+            }
+            for (uint32_t r0 = 0; r0 < A.rows; r0 += 8) {
+                const uint32_t r1 = std::min<uint32_t>(A.rows, r0 + 8);
+                int lo = 1 << 30, hi = -1;
+                for (uint32_t r = r0; r < r1; ++r) {
+                    for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
+                        lo = std::min(lo, idx_of[g][A.col_idx[q]]);
+                        hi = std::max(hi, idx_of[g][A.col_idx[q]]);
+                    }
+                    if (Bm.nnz() > 0)
+                        for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
+                            lo = std::min(lo, idx_of[g][Bm.col_idx[q]]);
+                            hi = std::max(hi, idx_of[g][Bm.col_idx[q]]);
+                        }
+                }
+                if (hi < 0) lo = hi = 0;   // rows without coefficients: one all-zero quad, so that their (zero) power is written
+                const int t_first = lo / CB_C, t_last = hi / CB_C;
+                int wsel = -1;
+                for (int w = 0; w < 8; ++w)
+                    if (busy_until[w] < t_first && (wsel < 0 || work[w] < work[wsel])) wsel = w;
+                if (wsel < 0) {
+                    t->f2_ok = false;
+                    break;
+                }
+                busy_until[wsel] = t_last;
+                for (int tt = t_first; tt <= t_last; ++tt) {
+                    const int c_lo = std::max(lo, tt * CB_C) - tt * CB_C, c_hi = std::min(hi, tt * CB_C + CB_C - 1) - tt * CB_C;
+                    const int q0 = c_lo / 4, q1 = c_hi / 4;
+                    const int nq = q1 - q0 + 1;
+                    const int boff = (int)(f2_B.size() / 64);
+                    f2_B.resize(f2_B.size() + (size_t)nq * 64, make_float2(0.0f, 0.0f));
+                    work[wsel] += nq;
+                    const int flags = (tt == t_first ? 1 : 0) | (tt == t_last ? 2 : 0);
+                    f2_segs[(size_t)(BG.tile0 + tt) * 8 + wsel] =
+                        make_int4(boff, q0 | (nq << 8) | (flags << 16) | ((int)(r1 - r0) << 24), (int)(groups[g].first_bin + r0), 0);
+                    // lane (n = l & 15: part = n >> 3, row = n & 7; kq = l >> 4) of quad q: column 4 (q0 + q) + kq of the tile
+                    auto at = [&](int ci, int part, int row) -> float2& {   // ci: the group's compressed column
+                        const int cl = ci - tt * CB_C;
+                        return f2_B[((size_t)boff + (cl / 4 - q0)) * 64 + (cl & 3) * 16 + part * 8 + row];
+                    };
+                    for (uint32_t r = r0; r < r1; ++r) {
+                        const int row = (int)(r - r0);
+                        for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
+                            const int ci = idx_of[g][A.col_idx[q]];
+                            if (ci / CB_C != tt) continue;
+                            const double ar_ = A.values[q].re, ai_ = A.values[q].im;
+                            const float vr = (float)(ar_ * rho[g][ci].first - ai_ * rho[g][ci].second);
+                            const float vi = (float)(ar_ * rho[g][ci].second + ai_ * rho[g][ci].first);
+                            // y += v X: re += vr Xr - vi Xi, im += vi Xr + vr Xi   (.x multiplies Re X, .y multiplies Im X)
+                            at(ci, 0, row).x += vr;
+                            at(ci, 0, row).y += -vi;
+                            at(ci, 1, row).x += vi;
+                            at(ci, 1, row).y += vr;
+                        }
+                        if (Bm.nnz() > 0)
+                            for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
+                                const int ci = idx_of[g][Bm.col_idx[q]];
+                                if (ci / CB_C != tt) continue;
+                                const double br_ = Bm.values[q].re, bi_ = Bm.values[q].im;
+                                const float wr = (float)(br_ * rho[g][ci].first - bi_ * rho[g][ci].second);
+                                const float wi = (float)(br_ * rho[g][ci].second + bi_ * rho[g][ci].first);
+                                // y += conj(w X): re += wr Xr - wi Xi, im += -wi Xr - wr Xi
+                                at(ci, 0, row).x += wr;
+                                at(ci, 0, row).y += -wi;
+                                at(ci, 1, row).x += -wi;
+                                at(ci, 1, row).y += -wr;
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (f2_B.empty()) f2_B.resize(64, make_float2(0.0f, 0.0f));
+    t->h_f2_segs = f2_segs;
     t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
               up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
-              up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3);
+              up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
+              (!t->f2_ok || (up(&t->d_E16, E16) && up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -1701,7 +1827,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     // contiguous region (and a column step is a constant 512 bytes); X_PAD_COLS zeroed columns close every tile
     const int xcp = xc + X_PAD_COLS;
     const size_t x_bytes = (chunk + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
-    if (t->x_cap < x_bytes) {
+    // the one-kernel form (vqt_fused2.hpp) keeps the spectrum on chip: no X workspace at all
+    static const int f2_env = getenv("PVQ_FUSED2") ? atoi(getenv("PVQ_FUSED2")) : 1;   // developer knob: 0 = the two-kernel form
+    static const bool fuse_env0 = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));
+    const bool use_f2 = f2_env && fuse_env0 && t->f2_ok && !gemm_split_bf16_ && t->n_groups <= 8;
+    if (!use_f2 && t->x_cap < x_bytes) {
         if (t->d_X) PVQ_HIP(hipFree(t->d_X));
         t->d_X = nullptr; t->x_cap = 0;
         PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_X), x_bytes));
@@ -1749,6 +1879,18 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     const int nb = (int)n_bins();
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     float2* X = t->d_X;
+    const size_t pw_stride = (chunk + 63) / 64 * 64;
+    if (use_f2) {
+        const size_t pw_bytes = (size_t)n_bins() * pw_stride * sizeof(float);
+        if (t->pw_cap < pw_bytes) {
+            if (t->d_pw) PVQ_HIP(hipFree(t->d_pw));
+            t->d_pw = nullptr; t->pw_cap = 0;
+            PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_pw), pw_bytes));
+            t->pw_cap = pw_bytes;
+        }
+        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_fused2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS_BYTES));
+        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_fused2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS_BYTES));
+    }
     for (size_t c = 0; c < n_chunks; ++c) {
         const size_t fbeg = c * chunk;
         const size_t nf = std::min(chunk, n_frames - fbeg);
@@ -1761,6 +1903,102 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         const float* pcm_base = d_pcm + rebase;
         const unsigned pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
         const long long base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
+        if (use_f2) {
+            // unit list: (window group, 256-block row tile), frame-stripe order as for the two-kernel form (a stripe of 2 048
+            // frames belongs to one XCD: workgroup b runs on XCD b & 7), kept per launch size
+            BlockDftTables::UnitList* ul = nullptr;
+            for (auto& u : t->f2_units)
+                if (u.nf == (int)nf) ul = &u;
+            if (!ul) {
+                ul = &t->f2_units[t->f2_units_next];
+                t->f2_units_next ^= 1;
+                const int FS = 2048;
+                std::vector<std::vector<int4>> q(8);
+                double gm = 0.0, dm = 0.0;
+                for (int g = 0; g < t->n_groups; ++g) {
+                    const BlockGroup& G = t->groups[g];
+                    const int S = 257 - G.nb_f;
+                    double dq = 0.0;
+                    for (int tt = 0; tt < G.n_tiles; ++tt)
+                        for (int w = 0; w < 8; ++w) dq += (t->h_f2_segs[(size_t)(G.tile0 + tt) * 8 + w].y >> 8) & 0xff;
+                    for (int f0 = 0; f0 < (int)nf; f0 += S) {
+                        q[(f0 / FS) & 7].push_back(make_int4(g, f0, 0, f0 / FS));
+                        gm += (double)G.n_tiles * 8 * 256;   // 8 waves x 256 MFMAs per column tile
+                        dm += dq * 32;                       // 16 frame tiles x (Re, Im) per column quad
+                    }
+                }
+                size_t L = 0;
+                for (auto& v : q) {
+                    std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });
+                    L = std::max(L, v.size());
+                }
+                std::vector<int4> list(8 * L, make_int4(0, 0x3FFFFFFF, 0, 0));   // padding entries: past every group's frames
+                for (int x = 0; x < 8; ++x)
+                    for (size_t i = 0; i < q[x].size(); ++i) list[i * 8 + x] = q[x][i];
+                if (ul->cap < list.size()) {
+                    if (ul->d) PVQ_HIP(hipFree(ul->d));
+                    ul->d = nullptr; ul->cap = 0;
+                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&ul->d), list.size() * sizeof(int4)));
+                    ul->cap = list.size();
+                }
+                PVQ_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read this slot
+                PVQ_HIP(hipMemcpy(ul->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
+                ul->nf = (int)nf;
+                ul->blocks = (int)list.size();
+                ul->gemm_mfma = gm;
+                ul->dots_mfma = dm;
+            }
+            F2Args fa;
+            fa.pcm_base = pcm_base;
+            fa.pcm_bytes = pcm_bytes;
+            fa.E16 = t->d_E16;
+            fa.K = (int)hop;
+            fa.n_frames = (int)nf;
+            fa.base = base;
+            fa.units = ul->d;
+            fa.groups = t->d_groups;
+            fa.comb_tw = t->d_comb_tw;
+            fa.segs = t->d_f2_segs;
+            fa.B2 = t->d_f2_B;
+            fa.pw = t->d_pw;
+            fa.pw_stride = (int)pw_stride;
+            fa.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
+            fa.n_bins = nb;
+            fa.clk = nullptr;
+            // flop the kernel's matrix instructions issue (v_mfma_f32_16x16x4_f32: 2 048 each): GEMM tiles + kernel-product quads
+            last_gemm_flop_ = (ul->gemm_mfma + ul->dots_mfma) * 2048.0;
+            if (profiling_) {
+                const size_t need = ((size_t)ul->blocks / 16 + 1) * 4 * sizeof(unsigned long long);
+                if (t->clk_cap < need) {
+                    if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
+                    t->d_clk = nullptr; t->clk_cap = 0;
+                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_clk), need));
+                    t->clk_cap = need;
+                }
+                PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
+                t->clk_n = ul->blocks / 16 + 1;
+                fa.clk = t->d_clk;
+            }
+            slot_begin(SLOT_BLOCKDFT_GEMM, stream);
+            if (fa.out_cplx)
+                hipLaunchKernelGGL(blockdft_fused2<true>, dim3(ul->blocks), dim3(512), F2_LDS_BYTES, stream, fa);
+            else
+                hipLaunchKernelGGL(blockdft_fused2<false>, dim3(ul->blocks), dim3(512), F2_LDS_BYTES, stream, fa);
+            slot_end(SLOT_BLOCKDFT_GEMM, stream);
+            PowArgs pa;
+            pa.pw = t->d_pw;
+            pa.pw_stride = (int)pw_stride;
+            pa.b = BandArgs{};
+            pa.b.n_frames = (int)nf;
+            pa.b.n_bins = nb;
+            pa.b.ldb = nb | 1;
+            pa.b.out_db = d_out_db + fbeg * nb;
+            pa.b.status = dev_->d_status;
+            slot_begin(SLOT_BLOCKDFT_DOTS, stream);
+            hipLaunchKernelGGL(power_rows_to_db, dim3((unsigned)((nf + 31) / 32)), dim3(256), sizeof(float) * 32 * pa.b.ldb, stream, pa);
+            slot_end(SLOT_BLOCKDFT_DOTS, stream);
+            continue;
+        }
         if (fused) {
             GemmTreeArgs fa;
             fa.pcm_base = pcm_base;
