@@ -113,7 +113,7 @@ struct BlockDftTables {
         int real = 0;   // entries that are tiles (the rest pads the eight per-XCD queues to one length)
     } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
     int tile_list_next = 0;
-    unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch
+    unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0, clk_per = 4;   // K-loop clock samples of the last profiled launch
     // one-kernel form (vqt_fused2.hpp): E in 16x16x4 B-operand order, per (column tile, wave) kernel-product segments and their
     // coefficients, the unit list of the last launch size, the power rows
     bool f2_ok = false;
@@ -1372,12 +1372,19 @@ static inline float host_from_bf16(uint16_t h) {
 float Vqt::last_sclk_mhz() {
     if (!dev_ || !dev_->block || !dev_->block->d_clk || dev_->block->clk_n <= 0) return 0.0f;
     BlockDftTables* t = dev_->block;
-    std::vector<unsigned long long> h((size_t)t->clk_n * 4);
+    const int per = t->clk_per;   // 4 slots per sample (two-kernel form) or 16 (one-kernel form: + per-pass stamps)
+    std::vector<unsigned long long> h((size_t)t->clk_n * per);
     if (hipSetDevice(device_id_) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0.0f;
     if (hipMemcpy(h.data(), t->d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0.0f;
     std::vector<double> r;
     for (int i = 0; i < t->clk_n; ++i)
-        if (h[4 * i + 3] > h[4 * i + 1]) r.push_back(100.0 * (double)(h[4 * i + 2] - h[4 * i]) / (double)(h[4 * i + 3] - h[4 * i + 1]));
+        if (h[per * i + 3] > h[per * i + 1]) r.push_back(100.0 * (double)(h[per * i + 2] - h[per * i]) / (double)(h[per * i + 3] - h[per * i + 1]));
+    if (const char* dump = getenv("PVQ_F2_STAMPS")) {   // developer knob: raw stamps of the sampled workgroups
+        if (FILE* fp = fopen(dump, "wb")) {
+            fwrite(h.data(), 8, h.size(), fp);
+            fclose(fp);
+        }
+    }
     if (r.empty()) return 0.0f;
     std::sort(r.begin(), r.end());
     return (float)r[r.size() / 2];
@@ -1965,10 +1972,12 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
             fa.n_bins = nb;
             fa.clk = nullptr;
+            static const int f2_exp = getenv("PVQ_F2_EXP") ? atoi(getenv("PVQ_F2_EXP")) : 0;
+            fa.exp = f2_exp;
             // flop the kernel's matrix instructions issue (v_mfma_f32_16x16x4_f32: 2 048 each): GEMM tiles + kernel-product quads
             last_gemm_flop_ = (ul->gemm_mfma + ul->dots_mfma) * 2048.0;
             if (profiling_) {
-                const size_t need = ((size_t)ul->blocks / 16 + 1) * 4 * sizeof(unsigned long long);
+                const size_t need = ((size_t)ul->blocks / 16 + 1) * 16 * sizeof(unsigned long long);
                 if (t->clk_cap < need) {
                     if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
                     t->d_clk = nullptr; t->clk_cap = 0;
@@ -1977,6 +1986,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 }
                 PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
                 t->clk_n = ul->blocks / 16 + 1;
+                t->clk_per = 16;
                 fa.clk = t->d_clk;
             }
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
@@ -2099,6 +2109,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 }
                 PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
                 t->clk_n = off / 64 + 1;
+                t->clk_per = 4;
                 fa.clk = t->d_clk;
             }
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);

@@ -48,6 +48,7 @@ struct F2Args {
     float2* out_cplx;         // optional [n_frames][n_bins]
     int n_bins;
     unsigned long long* clk;  // profiling only: every 16th workgroup stores (shader clock, 100 MHz clock) around one iteration
+    int exp;                  // developer knob PVQ_F2_EXP (timing experiments, wrong results): 1 no operand loads in the loop, 2 no side work, 4 no per-pass barrier, 8 no E refill
 };
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
@@ -83,6 +84,8 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
     float4* El = reinterpret_cast<float4*>(f2_smem + F2_P_BYTES + F2_Q_BYTES);          // ring of two E quarters: [2][32 * 16]
     float2 (*tw)[CB_C] = reinterpret_cast<float2 (*)[CB_C]>(f2_smem + F2_P_BYTES + F2_Q_BYTES + 2 * F2_EQ_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.clk != nullptr && (blockIdx.x & 15) == 0 && tid == 0) a.clk[(blockIdx.x >> 4) * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+    const bool first_half = wave < 4;
     const int S = 257 - G.nb_f;                  // complete frames of the row tile
     const int levels = G.levels_f;
     const int n_ct = G.n_tiles;
@@ -140,17 +143,19 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
     // 32 MFMAs: k group gq (the E quarter gq / 2 sits in ring slot (gq / 2) & 1)
     auto gemm_group = [&](int buf, int gq) {
         const float4* e = El + ((gq >> 1) & 1) * (32 * 16) + (16 * (gq & 1) + 4 * kq) * 16 + m16;
+        float4 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = e[t * 16];   // all four operand reads in flight before the first MFMA
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float4 b = e[t * 16];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const float sm = fr[buf][mt][t] + bk[buf][mt][3 - t];
                 const float df = fr[buf][mt][t] - bk[buf][mt][3 - t];
-                accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b.x, accR[mt][0], 0, 0, 0);
-                accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b.y, accR[mt][1], 0, 0, 0);
-                accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b.z, accI[mt][0], 0, 0, 0);
-                accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b.w, accI[mt][1], 0, 0, 0);
+                accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].x, accR[mt][0], 0, 0, 0);
+                accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].y, accR[mt][1], 0, 0, 0);
+                accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].z, accI[mt][0], 0, 0, 0);
+                accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].w, accI[mt][1], 0, 0, 0);
             }
         }
     };
@@ -211,11 +216,14 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
     // kernel product of this wave's block with the tile's columns
     f32x4m dacc[16];                             // 16 frame tiles x (8 bins x (re, im)): the block's partial sums over the column tiles
     int4 seg = make_int4(0, 0, 0, 0);
-    auto seg_open = [&](int ct) {
-        const int4 sg = a.segs[(size_t)(G.tile0 + ct) * 8 + wave];
-        seg.x = __builtin_amdgcn_readfirstlane(sg.x);
-        seg.y = __builtin_amdgcn_readfirstlane(sg.y);
-        seg.z = __builtin_amdgcn_readfirstlane(sg.z);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto seg_open = [&](int ct) {                // scalar loads: no vector-memory traffic
+        const int4 sg = a.segs[(size_t)(G.tile0 + ct) * 8 + wave_s];
+        seg.x = sg.x;
+        seg.y = sg.y;
+        seg.z = sg.z;
+    };
+    auto seg_clear = [&]() {
         if (((seg.y >> 8) & 0xff) != 0 && ((seg.y >> 16) & 1)) {
 #pragma unroll
             for (int ft = 0; ft < 16; ++ft)
@@ -223,17 +231,34 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
                 for (int r = 0; r < 4; ++r) dacc[ft][r] = 0.0f;
         }
     };
-    auto dots_quads = [&](int qa, int qb) {      // quads qa .. qb - 1 of the segment
-        const int q0 = seg.y & 0xff, nq = (seg.y >> 8) & 0xff;
-        for (int q = qa; q < qb && q < nq; ++q) {
-            const float2 b = a.B2[(size_t)(seg.x + q) * 64 + lane];
-            const float2* xcol = &Xt[m16][4 * (q0 + q) + kq];
+    // the coefficients of the four quads a pass may walk are fetched at the top of the pass, unconditionally (clamped), so that
+    // every pass issues the same vector-memory instructions and the compiler's count of loads in flight stays exact
+    float2 bq[4];
+    auto b_load = [&](int pr) {
+        const int nq = (seg.y >> 8) & 0xff;
+        const int qmax = nq > 0 ? nq - 1 : 0;
 #pragma unroll
-            for (int ft = 0; ft < 16; ++ft) {
-                const float2 x = xcol[ft * 16 * F2_LDP];
-                dacc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, b.x, dacc[ft], 0, 0, 0);
-                dacc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, b.y, dacc[ft], 0, 0, 0);
-                if ((ft & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four operand reads in flight, not sixteen
+        for (int i = 0; i < 4; ++i) {
+            const int q = min(4 * (pr & 1) + i, qmax);
+            bq[i] = a.B2[(size_t)(seg.x + q) * 64 + lane];
+        }
+    };
+    auto dots_quads = [&](int qa, int i0) {      // quads qa, qa + 1 of the segment (coefficients bq[i0], bq[i0 + 1])
+        const int q0 = seg.y & 0xff, nq = (seg.y >> 8) & 0xff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (qa + i >= nq) break;
+            const float2 b = bq[i0 + i];
+            const float2* xcol = &Xt[m16][4 * (q0 + qa + i) + kq];
+#pragma unroll
+            for (int f4 = 0; f4 < 16; f4 += 4) {
+                float2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = xcol[(f4 + u) * 16 * F2_LDP];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dacc[f4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].x, b.x, dacc[f4 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dacc[f4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].y, b.y, dacc[f4 + u], 0, 0, 0);
             }
         }
     };
@@ -280,21 +305,21 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
             }
         }
     };
-    // the side work on tile ct (the tile in LDS) in eight steps, two per pair of GEMM slots
-    auto side_even = [&](int pr, int ct) {
+    // the side work on the tile in LDS in eight steps, two per pair of GEMM slots
+    auto side_even = [&](int pr) {
         switch (pr) {   // workgroup-uniform
             case 0: tree_a(0); break;
             case 1: tree_c(0); break;
-            case 2: seg_open(ct); dots_quads(0, 2); break;
-            default: dots_quads(4, 6); break;
+            case 2: seg_clear(); dots_quads(0, 0); break;
+            default: dots_quads(4, 0); break;
         }
     };
     auto side_odd = [&](int pr) {
         switch (pr) {
             case 0: tree_a(1); break;
             case 1: tree_c(1); break;
-            case 2: dots_quads(2, 4); break;
-            default: dots_quads(6, 8); dots_close(); break;
+            case 2: dots_quads(2, 2); break;
+            default: dots_quads(6, 2); break;
         }
     };
 
@@ -314,29 +339,44 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
     for (int ct = 0; ct <= n_ct; ++ct) {         // iteration ct: GEMM of tile ct beside the side work on tile ct - 1
         const bool do_gemm = ct < n_ct, do_side = ct > 0;
         if (a.clk != nullptr && ct == 1 && (blockIdx.x & 15) == 0 && tid == 0) {
-            a.clk[(blockIdx.x >> 4) * 4 + 0] = __builtin_amdgcn_s_memtime();
-            a.clk[(blockIdx.x >> 4) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            a.clk[(blockIdx.x >> 4) * 16 + 0] = __builtin_amdgcn_s_memtime();
+            a.clk[(blockIdx.x >> 4) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
         }
         if (do_gemm) zero_acc();
+        if (do_side) seg_open(ct - 1);
+        const int ct_e = ct + 1 < n_ct ? ct + 1 : n_ct - 1;   // the tile whose E quarters passes 2 and 3 fetch (clamped: fetched, not used, at the end)
+        const int ct_c = ct < n_ct ? ct : n_ct - 1;
         for (int pr = 0; pr < 4; ++pr) {          // two GEMM slots (k groups 2 pr, 2 pr + 1) per pass: buffer indices stay static
+            if (a.clk != nullptr && ct == 1 && (blockIdx.x & 15) == 0 && tid == 0) a.clk[(blockIdx.x >> 4) * 16 + 4 + pr] = __builtin_amdgcn_s_memrealtime();
+            // Every pass issues the same vector-memory instructions whether or not their data is used (the drain iteration,
+            // the last tile): with no branch around them the compiler's count of loads in flight is exact and its waits fall
+            // on loads issued a slot earlier, not on the ones just issued.
             // the E quarter that takes this pass's ring slot once the pass is over: quarter pr + 2 of this tile, or quarter
             // pr - 2 of the next one
-            const bool e_next = do_gemm && (pr < 2 || ct + 1 < n_ct);
-            if (e_next) e_load(pr < 2 ? ct : ct + 1, (pr + 2) & 3);
-            if (do_gemm) load_group(1, 2 * pr + 1);
-            if (do_side) side_even(pr, ct - 1);
+            if (!(a.exp & 8)) e_load(pr < 2 ? ct_c : ct_e, (pr + 2) & 3);
+            if (!(a.exp & 1)) load_group(1, 2 * pr + 1);
+            b_load(pr);
+            // waves w and w + 4 share a SIMD: the first four run their step of the side work before their 32 MFMAs, the other
+            // four behind them, so that one wave of a SIMD feeds the matrix pipe while its partner is in vector / LDS code
+            const bool side_on = do_side && !(a.exp & 2);
+            if (side_on && first_half) side_even(pr);
             __builtin_amdgcn_sched_barrier(0);
             if (do_gemm) gemm_group(0, 2 * pr);
-            if (do_gemm) load_group(0, pr < 3 ? 2 * pr + 2 : 0);   // after the last pass: k group 0 again, for the next tile
-            if (do_side) side_odd(pr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (side_on && !first_half) side_even(pr);
+            if (!(a.exp & 1)) load_group(0, pr < 3 ? 2 * pr + 2 : 0);   // after the last pass: k group 0 again, for the next tile
+            if (side_on && first_half) side_odd(pr);
             __builtin_amdgcn_sched_barrier(0);
             if (do_gemm) gemm_group(1, 2 * pr + 1);
-            __syncthreads();   // the pass's E quarter is free; tree steps hand rows between threads
-            if (e_next) e_store(pr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (side_on && !first_half) side_odd(pr);
+            if (!(a.exp & 4)) __syncthreads();   // the pass's E quarter is free; tree steps hand rows between threads
+            if (!(a.exp & 8)) e_store(pr);
         }
+        if (do_side) dots_close();   // stores: behind the passes, so that they do not sit between a pass's loads and their use
         if (a.clk != nullptr && ct == 1 && (blockIdx.x & 15) == 0 && tid == 0) {
-            a.clk[(blockIdx.x >> 4) * 4 + 2] = __builtin_amdgcn_s_memtime();
-            a.clk[(blockIdx.x >> 4) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            a.clk[(blockIdx.x >> 4) * 16 + 2] = __builtin_amdgcn_s_memtime();
+            a.clk[(blockIdx.x >> 4) * 16 + 3] = __builtin_amdgcn_s_memrealtime();
         }
         // (the barrier that ends the last pass: tile ct - 1 is done with, its place is taken by tile ct)
         if (do_gemm) {
@@ -354,6 +394,11 @@ __device__ __forceinline__ void f2_unit(const F2Args& a, unsigned char* f2_smem,
             }
         }
         __syncthreads();
+        if (a.clk != nullptr && ct == 1 && (blockIdx.x & 15) == 0 && tid == 0) a.clk[(blockIdx.x >> 4) * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (a.clk != nullptr && (blockIdx.x & 15) == 0 && tid == 0) {
+        a.clk[(blockIdx.x >> 4) * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+        a.clk[(blockIdx.x >> 4) * 16 + 10] = (unsigned long long)n_ct;
     }
 }
 
