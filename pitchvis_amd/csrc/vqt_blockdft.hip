@@ -116,7 +116,8 @@ struct BlockDftTables {
     unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0, clk_per = 4;   // K-loop clock samples of the last profiled launch
     // one-kernel form (vqt_fused2.hpp): E in 16x16x4 B-operand order, per (column tile, wave) kernel-product segments and their
     // coefficients, the unit list of the last launch size, the power rows
-    bool f2_ok = false;
+    bool f2_ok = false;   // the one-kernel form applies (hop 256, windows of <= 64 blocks, every group colours with 8 waves)
+    bool t2_ok = false;   // the pipelined GEMM + tree applies (hop 256, windows of <= 64 blocks)
     float4* d_E16 = nullptr;
     int4* d_f2_segs = nullptr;
     float2* d_f2_B = nullptr;
@@ -1349,6 +1350,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
 
 }  // namespace pvq
 #include "vqt_fused2.hpp"
+#include "vqt_gemm_tree2.hpp"
 namespace pvq {
 
 // ------------------------------------------------------------------------------------------------
@@ -1707,8 +1709,9 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     std::vector<float4> E16;
     std::vector<int4> f2_segs((size_t)tile * 8, make_int4(0, 0, 0, 0));
     std::vector<float2> f2_B;
-    t->f2_ok = hop == 256 && t->nb_max <= 64;
-    if (t->f2_ok) {
+    t->t2_ok = hop == 256 && t->nb_max <= 64;
+    t->f2_ok = t->t2_ok;
+    if (t->t2_ok) {
         const size_t K2 = hop / 2;
         E16.resize((size_t)tile * K2 * 16);
         for (int tt = 0; tt < tile; ++tt)
@@ -1809,7 +1812,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
               up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
-              (!t->f2_ok || (up(&t->d_E16, E16) && up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
+              (!t->t2_ok || (up(&t->d_E16, E16) && up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -1835,9 +1838,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     const int xcp = xc + X_PAD_COLS;
     const size_t x_bytes = (chunk + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
     // the one-kernel form (vqt_fused2.hpp) keeps the spectrum on chip: no X workspace at all
-    static const int f2_env = getenv("PVQ_FUSED2") ? atoi(getenv("PVQ_FUSED2")) : 1;   // developer knob: 0 = the two-kernel form
+    static const int f2_env = getenv("PVQ_FUSED2") ? atoi(getenv("PVQ_FUSED2")) : 0;   // developer knob: 1 = the one-kernel form (experiment: parity-green, slower)
+    static const int t2_env = getenv("PVQ_GEMM_TREE2") ? atoi(getenv("PVQ_GEMM_TREE2")) : 0;   // developer knob: 1 = the pipelined blockdft_gemm_tree2 instead of blockdft_gemm_tree (experiment: parity-green, slower)
     static const bool fuse_env0 = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));
     const bool use_f2 = f2_env && fuse_env0 && t->f2_ok && !gemm_split_bf16_ && t->n_groups <= 8;
+    const bool use_t2 = !use_f2 && t2_env && fuse_env0 && t->t2_ok && !gemm_split_bf16_ && t->n_groups <= 8;
     if (!use_f2 && t->x_cap < x_bytes) {
         if (t->d_X) PVQ_HIP(hipFree(t->d_X));
         t->d_X = nullptr; t->x_cap = 0;
@@ -1898,6 +1903,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_fused2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS_BYTES));
         PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_fused2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS_BYTES));
     }
+    if (use_t2) PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_gemm_tree2), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
     for (size_t c = 0; c < n_chunks; ++c) {
         const size_t fbeg = c * chunk;
         const size_t nf = std::min(chunk, n_frames - fbeg);
@@ -1910,10 +1916,10 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         const float* pcm_base = d_pcm + rebase;
         const unsigned pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
         const long long base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
-        if (use_f2) {
+        BlockDftTables::UnitList* ul = nullptr;
+        if (use_f2 || use_t2) {
             // unit list: (window group, 256-block row tile), frame-stripe order as for the two-kernel form (a stripe of 2 048
             // frames belongs to one XCD: workgroup b runs on XCD b & 7), kept per launch size
-            BlockDftTables::UnitList* ul = nullptr;
             for (auto& u : t->f2_units)
                 if (u.nf == (int)nf) ul = &u;
             if (!ul) {
@@ -1955,6 +1961,8 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 ul->gemm_mfma = gm;
                 ul->dots_mfma = dm;
             }
+        }
+        if (use_f2) {
             F2Args fa;
             fa.pcm_base = pcm_base;
             fa.pcm_bytes = pcm_bytes;
@@ -2009,7 +2017,39 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             slot_end(SLOT_BLOCKDFT_DOTS, stream);
             continue;
         }
-        if (fused) {
+        if (use_t2) {
+            T2Args ta;
+            ta.pcm_base = pcm_base;
+            ta.pcm_bytes = pcm_bytes;
+            ta.E16 = t->d_E16;
+            ta.K = (int)hop;
+            ta.n_frames = (int)nf;
+            ta.base = base;
+            ta.units = ul->d;
+            ta.groups = t->d_groups;
+            ta.comb_tw = t->d_comb_tw;
+            ta.X = X;
+            ta.x_bytes = (unsigned)std::min<size_t>(x_bytes, 0x7FFFFFF0u);
+            ta.xcp = xcp;
+            ta.clk = nullptr;
+            last_gemm_flop_ = ul->gemm_mfma * 2048.0;   // v_mfma_f32_16x16x4_f32: 2 048 flop each
+            if (profiling_) {
+                const size_t need = ((size_t)ul->blocks / 16 + 1) * 16 * sizeof(unsigned long long);
+                if (t->clk_cap < need) {
+                    if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
+                    t->d_clk = nullptr; t->clk_cap = 0;
+                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_clk), need));
+                    t->clk_cap = need;
+                }
+                PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
+                t->clk_n = ul->blocks / 16 + 1;
+                t->clk_per = 16;
+                ta.clk = t->d_clk;
+            }
+            slot_begin(SLOT_BLOCKDFT_GEMM, stream);
+            hipLaunchKernelGGL(blockdft_gemm_tree2, dim3(ul->blocks), dim3(512), T2_LDS_BYTES, stream, ta);
+            slot_end(SLOT_BLOCKDFT_GEMM, stream);
+        } else if (fused) {
             GemmTreeArgs fa;
             fa.pcm_base = pcm_base;
             fa.pcm_bytes = pcm_bytes;
