@@ -107,7 +107,9 @@ def test_vqt_bandwidths_full_sweep(algo):
             f"margin {mx.max() - sm.min():.3f} < 3.0 | oracle {wmx.max():.3f} / {wdb.sum(axis=1, dtype=np.float32).min():.3f} | "
             f"max |dB_gpu - dB_oracle| {np.abs(db - wdb).max():.2e}, on the strongest bin {np.abs(mx - wmx).max():.2e}")
     assert mx.max() - sm.min() < 3.0
-    assert (db.argmax(axis=1) == wdb.argmax(axis=1)).all()
+    # the strongest bin is the same one — or, where two neighbouring bins tie to within the dB parity tolerance, one of the two
+    gi = db.argmax(axis=1)
+    assert (wmx - wdb[np.arange(gi.size), gi] <= 2e-4).all()
     assert np.abs(mx - wmx).max() <= 2e-4
     assert np.abs(db - wdb).max() <= 1e-2
 
