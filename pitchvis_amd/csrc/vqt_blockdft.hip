@@ -212,6 +212,7 @@ struct GemmTreeArgs {
     const BlockGroup* groups;
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
+    const float4* E16;        // [column tile][k < K / 2][n < 16]: (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}): B operands of the 16x16x4 fp32 form
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
     unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader clock, 100 MHz clock) before and after its K loop
 };
@@ -284,7 +285,7 @@ __device__ __forceinline__ void fused_tree_register_levels(float2 (*A)[CB_C + 1]
     const int c = tid & (CB_C - 1), j0 = (tid >> 5) * 16;
     float2 v[16 + H];
 #pragma unroll
-    for (int i = 0; i < 16 + H; ++i) v[i] = (j0 + i < BM) ? A[j0 + i][c] : make_float2(0.0f, 0.0f);
+    for (int i = 0; i < 16 + H; ++i) v[i] = A[j0 + i][c];   // rows BM .. BM + 14 are spare rows of the tile (zeroed by the caller)
     int len = 16 + H;
 #pragma unroll
     for (int l = 0; l < R; ++l) {
@@ -471,10 +472,92 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
     }
 }
 
+// The same mirrored GEMM on v_mfma_f32_16x16x4_f32 (the form blockdft_gemm_tree runs).  A wave still owns 32 block rows x 32
+// complex columns (two 16-row tiles x (re, im) x two 16-column halves = 8 accumulators of 4 registers), but lane
+// (row = lane & 15, kq = lane >> 4) now fetches 4 consecutive samples of its row and the 4 mirrored ones with ONE 16-byte load
+// each: the four lanes of a row read one contiguous 64-byte run, 16 cache lines per load instruction where the 32x32x2 form's
+// lanes touch 64 — its address processing took as long as its MFMAs (16 vs 15.6 us per workgroup pair), which is what held a
+// workgroup running its K loop alone (its CU partner in its tree / store phase) at 63 % of the matrix pipe.  MFMA t of a k
+// group (16 mirrored sample pairs) takes sample 4 kq + t of every lane; B operand of lane (n, kq): row 16 g + 4 kq + t of the
+// E slice, (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}) as one 16-byte LDS read.  Operands double-buffered, one k group ahead.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+template <bool VEC, int BM>
+__device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
+                                                  f32x4a (&accR)[2][2], f32x4a (&accI)[2][2]) {
+    constexpr int THREADS = 2 * BM;
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+    const int K2 = a.K / 2;
+    long long jf0[2], jb0[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
+        jf0[mt] = row_lo + 4 * kq;
+        jb0[mt] = row_lo + a.K - 4 - 4 * kq;
+    }
+    float fr[2][2][4], bk[2][2][4];
+    auto load_group = [&](int buf, int g) {   // g: k group of the whole depth (16 sample pairs each)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (VEC) {
+                const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jf0[mt] * 4u + 64u * (unsigned)g), 0, 0);
+                const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jb0[mt] * 4u - 64u * (unsigned)g), 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    fr[buf][mt][t] = v[t];
+                    bk[buf][mt][t] = w[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long long xf = jf0[mt] + 16 * g + t, xb = jb0[mt] - 16 * g + t;
+                    fr[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xf >= 0 ? (unsigned)(xf * 4ll) : 0xFFFFFFFCu, 0, 0));
+                    bk[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xb >= 0 ? (unsigned)(xb * 4ll) : 0xFFFFFFFCu, 0, 0));
+                }
+            }
+        }
+    };
+    float4* El = reinterpret_cast<float4*>(smem);   // [rows][16]
+    auto mfma_group = [&](int buf, int gl) {        // gl: k group inside the staged slice
+        const float4* e = El + (16 * gl + 4 * kq) * 16 + m16;
+        float4 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = e[t * 16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float sm = fr[buf][mt][t] + bk[buf][mt][3 - t];
+                const float df = fr[buf][mt][t] - bk[buf][mt][3 - t];
+                accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].x, accR[mt][0], 0, 0, 0);
+                accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].y, accR[mt][1], 0, 0, 0);
+                accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].z, accI[mt][0], 0, 0, 0);
+                accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].w, accI[mt][1], 0, 0, 0);
+            }
+        }
+    };
+    load_group(0, 0);
+    for (int kc = 0; kc < K2; kc += FR_KC) {
+        const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
+        if (kc > 0) __syncthreads();   // every wave is done with the previous slice
+        for (int i = tid; i < rows * 16; i += THREADS) El[i] = e_tile[(size_t)kc * 16 + i];
+        __syncthreads();
+        const int ng = rows / 16, g0 = kc / 16;
+        for (int gl = 0; gl < ng; gl += 2) {   // two k groups per pass: buffer indices stay compile-time (rows is a multiple of 32)
+            load_group(1, g0 + gl + 1);
+            mfma_group(0, gl);
+            if (g0 + gl + 2 < K2 / 16) load_group(0, g0 + gl + 2);
+            mfma_group(1, gl + 1);
+        }
+    }
+}
+
 template <int BM>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 complex columns
 __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) {   // 4 waves per SIMD = two 512-thread (four 256-thread) workgroups per CU: at most 128 registers
     constexpr int B_FLOATS = FR_KC * FT_BN;
-    constexpr int P_FLOATS = BM * FT_LDP * 2;
+    constexpr int P_FLOATS = (BM + 15) * FT_LDP * 2;   // 15 spare rows: the register tree levels read their halo without a range check
     __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice, then the P tile
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -485,29 +568,27 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
     const long long s = a.base + T.G.s_rel;
     const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
-    const long long row0 = tile_lo + (long long)(wave * 32 + (lane & 31)) * a.K;
-    const int half = lane >> 5;
-    // the lane's front run x[16 half .. +15] and its mirror x[K - 16 - 16 half .. +15] (stage 0)
-    const long long off_f0 = row0 + 16 * half;
-    const long long off_b0 = row0 + a.K - 16 - 16 * half;
-    const float* e_tile = a.E + (size_t)nt * FT_BN;
-    f32x16 acc0, acc1;
+    const float4* e_tile = a.E16 + (size_t)nt * (a.K / 2) * 16;
+    f32x4a accR[2][2], accI[2][2];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        acc0[q] = 0.0f;
-        acc1[q] = 0.0f;
-    }
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accR[mt][np][r] = 0.0f;
+                accI[mt][np][r] = 0.0f;
+            }
     // the clock the chip holds under this kernel's MFMA load: shader-clock ticks over 100 MHz ticks across the K loop.  The
-    // start stamps go straight to memory so that nothing stays live in registers across the loop (the kernel sits at the
-    // 128-register edge of four waves per SIMD).
+    // start stamps go straight to memory so that nothing stays live in registers across the loop
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 0] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
     if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
-        fused_f32_kloop<true, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+        fused_f32_kloop16<true, BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
     else
-        fused_f32_kloop<false, BM>(a, smem, off_f0, off_b0, e_tile, tid, acc0, acc1);
+        fused_f32_kloop16<false, BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -515,12 +596,18 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     PVQ_STAMP(1);
     __syncthreads();   // the E slice is dead: the P' tile takes its place
     PVQ_STAMP(4);
-    // P' tile -> LDS as [row][32 complex + pad]  (C/D layout: col = lane & 31, row = (q&3) + 8(q>>2) + 4(lane>>5))
+    // P' tile -> LDS as [row][32 complex + pad]  (C/D layout of the 16x16 MFMA: column = lane & 15, rows 4 (lane >> 4) + r)
     float2 (*Pt)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);
+    {
+        const int m16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int row = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        Pt[row][lane & 31] = make_float2(acc0[q], acc1[q]);
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int np = 0; np < 2; ++np)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Pt[wave * 32 + mt * 16 + 4 * kq + r][np * 16 + m16] = make_float2(accR[mt][np][r], accI[mt][np][r]);
+        if (tid < 15 * FT_LDP) Pt[BM][tid] = make_float2(0.0f, 0.0f);   // the spare rows (Pt[BM][..] runs on through them)
     }
     __syncthreads();
     PVQ_STAMP(5);
@@ -582,7 +669,7 @@ constexpr int FB_BK = 32;
 template <int BM> struct FbGeom {
     static constexpr int PLANE = (BM + FT_BN) * FB_BK;            // bf16 elements of one plane: BM PCM rows, then 64 E^T rows
     static constexpr int STAGE_BYTES = 3 * PLANE * 2;             // 36 864 B at BM = 128
-    static constexpr int P_BYTES = BM * FT_LDP * 8;               // the P tile that aliases the staging area
+    static constexpr int P_BYTES = (BM + 15) * FT_LDP * 8;        // the P tile that aliases the staging area (+ 15 spare rows: the tree's halo reads need no range check)
     static constexpr int LDS_BYTES = STAGE_BYTES > P_BYTES ? STAGE_BYTES : P_BYTES;
 };
 // element offset of the 8-sample chunk `ch` (0..3) of row `row` inside a plane.  Rows are 64 bytes, unpadded; the
@@ -720,6 +807,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
         smem[row * (2 * FT_LDP) + bc] = acc0[q];
         smem[(row + 32) * (2 * FT_LDP) + bc] = acc1[q];
     }
+    if (tid < 15 * FT_LDP) reinterpret_cast<float2*>(smem)[BM * FT_LDP + tid] = make_float2(0.0f, 0.0f);   // the spare rows
     __syncthreads();
     fused_tree_store<BM>(smem, tw_lds, T, a, tid);
 }
@@ -1711,7 +1799,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     std::vector<float2> f2_B;
     t->t2_ok = hop == 256 && t->nb_max <= 64;
     t->f2_ok = t->t2_ok;
-    if (t->t2_ok) {
+    {   // E in the B-operand order of the 16x16x4 GEMM: [column tile][k < hop / 2][n < 16]: (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16})
         const size_t K2 = hop / 2;
         E16.resize((size_t)tile * K2 * 16);
         for (int tt = 0; tt < tile; ++tt)
@@ -1720,6 +1808,8 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                     const float* e = E.data() + m * ntot + (size_t)tt * GM_BN;
                     E16[((size_t)tt * K2 + m) * 16 + n] = make_float4(e[2 * n], e[2 * (n + 16)], e[2 * n + 1], e[2 * (n + 16) + 1]);
                 }
+    }
+    if (t->t2_ok) {
         // Kernel-product blocks of 8 bins -> waves: a block is open from the column tile of its first column to that of its
         // last; a wave holds one block's sums at a time, so blocks whose tile spans overlap need different waves (interval
         // colouring: possible with 8 waves iff no tile has more than 8 open blocks).  Among the free waves the one with the
@@ -1812,7 +1902,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
               up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
-              (!t->t2_ok || (up(&t->d_E16, E16) && up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
+              up(&t->d_E16, E16) && (!t->t2_ok || (up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -2129,6 +2219,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
             fa.Et = t->d_Et;
+            fa.E16 = t->d_E16;
             static const char* stamps_env = getenv("PVQ_STAMPS");   // developer knob: dump per-workgroup phase stamps once
             static bool stamps_done = false;
             const bool do_stamps = stamps_env && !stamps_done;
