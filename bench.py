@@ -266,7 +266,7 @@ def main():
                 "n_bins": N_BINS,
                 "algo": {P.ALGO_FFT: "fft", P.ALGO_BLOCKDFT: "blockdft"}.get(vqt.last_algo(), "auto"),
                 "gemm_arith": ("fp32 operands as 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate "
-                               "(error at fp32 rounding level, same parity bars)" if split else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
+                               "(error at fp32 rounding level, same parity bars)" if split else "fp32 MFMA v_mfma_f32_16x16x4_f32"),
                 "sharding": f"one stream, frames x{world}, halo {vqt.window_union - HOP} samples per shard, no collective",
             },
             "roofline": {

@@ -151,7 +151,7 @@ pvq_algo pvq_vqt_last_algo(const pvq_vqt *v);
  * same parity bars; PVQ_GEMM_BF16X3 writes each fp32 operand exactly as three bf16 terms and uses the bf16 matrix
  * cores (six exact partial products per fp32 product, dropped terms < 2^-24): ~10 % faster end to end. */
 typedef enum pvq_gemm_precision {
-    PVQ_GEMM_F32 = 0,     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+    PVQ_GEMM_F32 = 0,     /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32)  */
     PVQ_GEMM_BF16X3 = 1   /* split-bf16: 6 bf16 MFMAs per fp32 product block, error at fp32 rounding level */
 } pvq_gemm_precision;
 pvq_status pvq_vqt_set_gemm_precision(pvq_vqt *v, pvq_gemm_precision p);

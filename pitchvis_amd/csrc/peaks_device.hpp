@@ -38,7 +38,7 @@ struct PeakParamsDev {
 // bytes of LDS scratch one wave needs besides the frame itself
 __host__ __device__ inline size_t peaks_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return n /*cand*/ + n /*plist: n/2 u16*/ + (dist > 1 ? 2 * n /*keep[2]*/ + 2 * n /*compacted candidate list: n/2 + 1 u16*/ : 0);
+    return n /*cand*/ + n /*plist: n/2 u16*/ + (dist > 1 ? n /*keep*/ + 2 * n /*compacted candidate list: n/2 + 1 u16*/ : 0);
 }
 
 __device__ __forceinline__ float pk_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -249,7 +249,6 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     uint8_t* cand = scratch;
     uint16_t* plist = reinterpret_cast<uint16_t*>(scratch + npad);  // compacted peak bins, ascending
     uint8_t* keep0 = scratch + 2 * npad;
-    uint8_t* keep1 = keep0 + npad;
 
     // frame minimum: a peak of height h can only reach prominence P if fl(h - min) >= P, which
     // rejects the many low local maxima of a noisy frame without walking at all
@@ -273,9 +272,12 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.dist > 1) {
-        uint16_t* dl = reinterpret_cast<uint16_t*>(keep1 + npad);   // compacted candidate list
-        pk_distance_wave(x, n, cand, a.bass_min_height, a.dist, keep0, dl, lane);
-        pk_distance_wave(x, n, cand, a.peak_min_height, a.dist, keep1, dl, lane);
+        uint16_t* dl = reinterpret_cast<uint16_t*>(keep0 + npad);   // compacted candidate list
+        // find_peaks runs its distance rule once per height threshold (bass / general), but one evaluation at the lower threshold
+        // serves both: a candidate's fate depends only on candidates of higher priority (greater height), so the candidates
+        // between the two thresholds — the lowest of all — never change the verdict of one at or above the higher threshold,
+        // and the height test below removes them where they do not belong
+        pk_distance_wave(x, n, cand, fminf(a.bass_min_height, a.peak_min_height), a.dist, keep0, dl, lane);
     }
     float v[NK];
 #pragma unroll
@@ -289,7 +291,7 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
             const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
             const float H = bass ? a.bass_min_height : a.peak_min_height;
             const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
-            pre = xv >= H && (a.dist <= 1 || (bass ? keep0[i] : keep1[i])) && (!(P > 0.0f) || (xv - fmin_ >= P));
+            pre = xv >= H && (a.dist <= 1 || keep0[i]) && (!(P > 0.0f) || (xv - fmin_ >= P));
         }
         // most candidates are settled by the 16 samples on either side; the rest go to the exact wave test
         int st = 2;
@@ -365,7 +367,7 @@ __device__ __forceinline__ bool pk_is_top(const float* x, int i, float xv) {
 // LDS scratch of the lean routine besides the frame and its peak list: candidate list (u16), peak flags (u8)
 __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return 2 * n + (dist > 1 ? 3 * n /*local maxima, kept at the bass / general height*/ : 0);
+    return 2 * n + (dist > 1 ? 2 * n /*local maxima, survivors of the distance rule*/ : 0);
 }
 
 // plist: where the frame's peak bins go (ascending, room for n / 2 + 1 u16); n_peaks receives their number.  The
@@ -380,8 +382,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
     uint8_t* flag = scratch + npad;                                  // flag[bin] = 1 for a peak
     uint8_t* lmax = scratch + 2 * npad;                              // dist > 1 only: strict local maxima,
-    uint8_t* keep0 = lmax + npad;                                    //   survivors of the distance rule at the bass height,
-    uint8_t* keep1 = keep0 + npad;                                   //   and at the general height
+    uint8_t* keep0 = lmax + npad;                                    //   survivors of the distance rule (evaluated at the lower height threshold)
     float v[NK];
     float fmin_ = INF;
     bool plateau = false;
@@ -399,10 +400,9 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     }
     n_peaks = 0;
     if (__ballot(plateau)) return false;
-    if (DISTANCE) {   // find_peaks' distance rule runs before its prominence test, once per height threshold
-        pk_distance_wave(x, n, lmax, a.bass_min_height, a.dist, keep0, clist, lane);   // clist is free until step 1
-        pk_distance_wave(x, n, lmax, a.peak_min_height, a.dist, keep1, clist, lane);
-    }
+    if (DISTANCE)   // find_peaks' distance rule runs before its prominence test, once per height threshold: one evaluation at the
+                    // lower threshold serves both (see peaks_wave_nk); clist is free until step 1
+        pk_distance_wave(x, n, lmax, fminf(a.bass_min_height, a.peak_min_height), a.dist, keep0, clist, lane);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
 
@@ -419,7 +419,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
         bool pre = (i >= a.min_bin) && (i < n) && pk_is_top(x, i, xv) && (xv >= H) &&
                    (!(P > 0.0f) || (xv - fmin_ >= P));
-        if (DISTANCE && pre) pre = (bass ? keep0[i] : keep1[i]) != 0;
+        if (DISTANCE && pre) pre = keep0[i] != 0;
         const unsigned long long bm = __ballot(pre);
         if (pre) clist[n_cand + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)i;
         n_cand += __popcll(bm);
