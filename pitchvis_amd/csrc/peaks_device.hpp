@@ -195,6 +195,7 @@ __device__ __forceinline__ void pk_refine(const float* x, int p, const PeakParam
 // kept higher-priority neighbour and "kept" needs all of them removed — both verdicts stay true whatever happens later, so
 // it does not matter whether a lane sees a neighbour's state from before or after this step.
 // list: room for n / 2 + 1 u16 (strict local maxima and plateau tops are never adjacent).
+__device__ __forceinline__ void pk_distance_rounds(const float* x, int n, int dist, uint8_t* keep, const uint16_t* list, int n_list, int lane);
 __device__ __forceinline__ void pk_distance_wave(const float* x, int n, const uint8_t* cand, float min_height, int dist, uint8_t* keep,
                                                  uint16_t* list, int lane) {
     int n_list = 0;
@@ -206,31 +207,40 @@ __device__ __forceinline__ void pk_distance_wave(const float* x, int n, const ui
         if (c) list[n_list + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)i;
         n_list += __popcll(bm);
     }
+    pk_distance_rounds(x, n, dist, keep, list, n_list, lane);
+}
+// the rounds alone: keep[i] = 2 for the candidates (compacted in `list`, ascending), 0 elsewhere
+__device__ __forceinline__ void pk_distance_rounds(const float* x, int n, int dist, uint8_t* keep, const uint16_t* list, int n_list, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // branch-free rounds: the candidates' lanes run the same instruction stream whatever their neighbours are (per-lane
+    // `continue`s cost a pair of exec-mask updates each: the scalar unit was the busiest part of the peak kernel at 84 bins
+    // per octave)
     for (int round = 0; round < n; ++round) {   // terminates long before: every round decides at least one candidate
         bool any = false;
-        for (int k = lane; k < n_list; k += 64) {
-            const int i = list[k];
-            if (keep[i] != 2) continue;
+        for (int k0 = 0; k0 < n_list; k0 += 64) {
+            const int k = k0 + lane;
+            const bool valid = k < n_list;
+            const int i = valid ? (int)list[k] : 0;
+            const bool und = valid && keep[i] == 2;
             const float h = x[i];
             bool blocked = false, killed = false;
             for (int d = 1; d < dist; ++d) {
 #pragma unroll
                 for (int sgn = -1; sgn <= 1; sgn += 2) {
                     const int j = i + sgn * d;
-                    if (j < 0 || j >= n) continue;
-                    const uint8_t sj = keep[j];
-                    if (sj == 0) continue;
-                    const float hj = x[j];
-                    if (!(hj > h || (hj == h && j > i))) continue;   // lower priority: cannot remove this one
-                    if (sj == 1) killed = true;
-                    else blocked = true;
+                    const bool inb = j >= 0 && j < n;
+                    const int jc = inb ? j : i;
+                    const uint8_t sj = keep[jc];
+                    const float hj = x[jc];
+                    const bool hp = inb && sj != 0 && (hj > h || (hj == h && j > i));   // a live candidate of higher priority
+                    killed |= hp && sj == 1;
+                    blocked |= hp && sj == 2;
                 }
             }
-            if (killed) keep[i] = 0;
-            else if (!blocked) keep[i] = 1;
-            else any = true;
+            const uint8_t verdict = killed ? 0 : (blocked ? 2 : 1);
+            if (und) keep[i] = verdict;
+            any |= und && verdict == 2;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -364,51 +374,75 @@ __device__ __forceinline__ bool pk_is_top(const float* x, int i, float xv) {
     return (x[i + 1] < xv) && ((l < xv) || (l == xv && x[i - 2] < xv));
 }
 
-// LDS scratch of the lean routine besides the frame and its peak list: candidate list (u16), peak flags (u8)
+// LDS scratch of the lean routine besides the frame and its peak list: candidate list (u16), 64 mask words, distance-rule states (u8)
 __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return 2 * n + (dist > 1 ? 2 * n /*local maxima, survivors of the distance rule*/ : 0);
+    return n + 256 + (dist > 1 ? n /*survivors of the distance rule*/ : 0);
 }
 
-// plist: where the frame's peak bins go (ascending, room for n / 2 + 1 u16); n_peaks receives their number.  The
-// continuous outputs are NOT produced here: the caller refines the peaks of several frames side by side (full lanes).
+// plist: where the frame's peak bins go (ascending, room for npad / 2 u16; the last slot is a dump slot); n_peaks receives
+// their number.  The continuous outputs are NOT produced here: the caller refines the peaks of several frames side by side.
+// Written without per-lane branches: a predicated LDS store goes to a dump slot instead (peak positions are never adjacent and
+// never the first or last sample, so a frame holds at most npad / 2 - 1 of them and slot npad / 2 - 1 of either list is free),
+// range tests that the +INF sentinels around the frame already decide are left out, and the peak mask is gathered with one
+// LDS atomic per pass — every `if (lane-dependent) store` costs an exec-mask save / branch / restore on the scalar unit, which
+// was as busy as the vector unit here.
 template <int NK, bool DISTANCE>   // DISTANCE: min_distance > 1 (84 bins per octave)
 __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, uint16_t* plist, uint32_t& n_peaks, size_t frame,
                                                 const PeakParamsDev& a, int lane) {
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
     const int words = (n + 31) / 32;
+    const int dump = npad / 2 - 1;
     const float INF = __builtin_huge_valf();
     uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
-    uint8_t* flag = scratch + npad;                                  // flag[bin] = 1 for a peak
-    uint8_t* lmax = scratch + 2 * npad;                              // dist > 1 only: strict local maxima,
-    uint8_t* keep0 = lmax + npad;                                    //   survivors of the distance rule (evaluated at the lower height threshold)
+    uint32_t* maskw = reinterpret_cast<uint32_t*>(scratch + npad);   // the frame's peak mask, one word per lane
+    uint8_t* keep0 = scratch + npad + 256;                           // dist > 1 only: survivors of the distance rule (evaluated at the lower height threshold)
     float v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = INF;
     float fmin_ = INF;
     bool plateau = false;
+    const float hmin = fminf(a.bass_min_height, a.peak_min_height);
+    int n_dl = 0;
+    uint32_t topm = 0;   // bit k: this lane's bin of chunk k is a peak position (strict local maximum or second sample of a two-sample plateau)
+    static_assert(NK <= 32, "one bit per chunk");
+    maskw[lane] = 0;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
+        if ((k << 6) >= n) break;
         const int i = (k << 6) + lane;
-        v[k] = (i < n) ? x[i] : INF;
-        if (i < n) fmin_ = fminf(fmin_, v[k]);
+        const float xv = x[i], l2 = x[i - 2], l = x[i - 1], r = x[i + 1], r2 = x[i + 2];   // +INF outside the frame
+        v[k] = xv;
+        fmin_ = fminf(fmin_, xv);
         // a rise followed by two equal samples may start a plateau peak of three or more: leave those frames to the
         // generic code (two-sample plateaus — exact ties of neighbouring bins, a few per 10^5 noise frames — are taken
-        // here: their middle_position is the second sample)
-        plateau |= (i >= 1 && i < n - 2) && (x[i - 1] < v[k]) && (x[i + 1] == v[k]) && (x[i + 2] == v[k]);
-        if (i < npad) flag[i] = 0;
-        if (DISTANCE && i < npad) lmax[i] = (i >= 1 && i < n - 1 && pk_is_top(x, i, v[k])) ? 1 : 0;
+        // here: their middle_position is the second sample).  (i < n - 2: the sentinels equal each other)
+        plateau |= (i < n - 2) & (l < xv) & (r == xv) & (r2 == xv);
+        // peak position (pk_is_top): a fall after, and a rise before or a two-sample plateau ending here; the sentinels make the
+        // frame's first and last sample, and everything past them, fail by themselves
+        const bool top = (r < xv) & ((l < xv) | ((l == xv) & (l2 < xv)));
+        topm |= top ? (1u << k) : 0u;
+        if (DISTANCE) {   // the distance rule's candidates (peak positions at or above the lower height threshold), compacted on the way
+            const bool c = top & (xv >= hmin);
+            keep0[i] = c ? 2 : 0;
+            const unsigned long long bm = __ballot(c);
+            clist[c ? n_dl + (int)__popcll(bm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
+            n_dl += __popcll(bm);
+        }
     }
     n_peaks = 0;
     if (__ballot(plateau)) return false;
     if (DISTANCE)   // find_peaks' distance rule runs before its prominence test, once per height threshold: one evaluation at the
-                    // lower threshold serves both (see peaks_wave_nk); clist is free until step 1
-        pk_distance_wave(x, n, lmax, fminf(a.bass_min_height, a.peak_min_height), a.dist, keep0, clist, lane);
+                    // lower threshold serves both (see peaks_wave_nk); clist is free again from step 1 on
+        pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
 
     // 1. candidates of the whole frame, compacted: the window walk below then runs once per 64 candidates
     //    instead of once per 64 bins (a third of the bins are local maxima, far fewer pass height / range)
     uint32_t n_cand = 0;
+    const bool noPb = !(a.bass_min_prominence > 0.0f), noPg = !(a.peak_min_prominence > 0.0f);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         if ((k << 6) >= n) break;
@@ -417,11 +451,11 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
         const float H = bass ? a.bass_min_height : a.peak_min_height;
         const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
-        bool pre = (i >= a.min_bin) && (i < n) && pk_is_top(x, i, xv) && (xv >= H) &&
-                   (!(P > 0.0f) || (xv - fmin_ >= P));
-        if (DISTANCE && pre) pre = keep0[i] != 0;
+        const bool noP = bass ? noPb : noPg;
+        bool pre = (i >= a.min_bin) & (((topm >> k) & 1u) != 0) & (xv >= H) & (noP | (xv - fmin_ >= P));
+        if (DISTANCE) pre &= keep0[i] != 0;
         const unsigned long long bm = __ballot(pre);
-        if (pre) clist[n_cand + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        clist[pre ? (int)n_cand + (int)__popcll(bm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
         n_cand += __popcll(bm);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -431,7 +465,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
     uint32_t total = 0;
     for (uint32_t base = 0; base < n_cand; base += 64) {
         const bool have = base + lane < n_cand;
-        const int i = have ? (int)clist[base + lane] : a.min_bin;
+        const int i = have ? (int)clist[base + lane] : 0;   // idle lanes sit on the first sample, which is never a peak
         const float xv = x[i];
         const float P = (i <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
         // pL / pR: a sample higher than the peak has been met on that side (later samples no longer count)
@@ -467,23 +501,13 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
             if (lane == b) peak = ok;
         }
         const unsigned long long pm = __ballot(peak);
-        if (peak) {
-            plist[total + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)i;
-            flag[i] = 1;
-        }
+        plist[peak ? (int)total + (int)__popcll(pm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
+        __hip_atomic_fetch_or(&maskw[i >> 5], peak ? (1u << (i & 31)) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         total += __popcll(pm);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (a.mask) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            if ((k << 6) >= n) break;
-            const unsigned long long pm = __ballot(flag[(k << 6) + lane] != 0);
-            if (lane == 0 && 2 * k < words) a.mask[frame * words + 2 * k] = (uint32_t)pm;
-            if (lane == 1 && 2 * k + 1 < words) a.mask[frame * words + 2 * k + 1] = (uint32_t)(pm >> 32);
-        }
-    }
+    if (a.mask && lane < words) a.mask[frame * words + lane] = maskw[lane];
     if (a.count && lane == 0) a.count[frame] = total;
     n_peaks = total;
     return true;
