@@ -387,12 +387,12 @@ __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist)
 // range tests that the +INF sentinels around the frame already decide are left out, and the peak mask is gathered with one
 // LDS atomic per pass — every `if (lane-dependent) store` costs an exec-mask save / branch / restore on the scalar unit, which
 // was as busy as the vector unit here.
+// Part 1 (one frame): peak positions, the distance rule, and the frame's candidates compacted into its clist; n_cand receives
+// their number.  Returns false, with n_cand = 0, when the frame goes to the generic routine.
 template <int NK, bool DISTANCE>   // DISTANCE: min_distance > 1 (84 bins per octave)
-__device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* scratch, uint16_t* plist, uint32_t& n_peaks, size_t frame,
-                                                const PeakParamsDev& a, int lane) {
+__device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* scratch, uint32_t& n_cand_out, const PeakParamsDev& a, int lane) {
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
-    const int words = (n + 31) / 32;
     const int dump = npad / 2 - 1;
     const float INF = __builtin_huge_valf();
     uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
@@ -431,7 +431,7 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
             n_dl += __popcll(bm);
         }
     }
-    n_peaks = 0;
+    n_cand_out = 0;
     if (__ballot(plateau)) return false;
     if (DISTANCE)   // find_peaks' distance rule runs before its prominence test, once per height threshold: one evaluation at the
                     // lower threshold serves both (see peaks_wave_nk); clist is free again from step 1 on
@@ -458,14 +458,44 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
         clist[pre ? (int)n_cand + (int)__popcll(bm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
         n_cand += __popcll(bm);
     }
+    n_cand_out = n_cand;
+    return true;
+}
+
+// Part 2 (the FPW frames of a wave together): prominence of every candidate over a PK_PAD-sample window on both sides.  The
+// candidates of the wave's frames are walked side by side — a frame has ~30, so one pass of 64 lanes serves two frames.
+// x0 / scratch0 / plist0: frame 0's row, scratch and peak list; the next frame's lie row / scratch_stride / pl_cap further on.
+// total[g] receives frame g's number of peaks; mask and count are written for the frames with write[g] set.
+template <int NK, int FPW>
+__device__ __forceinline__ void peaks_lean_walk(const float* x0, int row, unsigned char* scratch0, int scratch_stride, uint16_t* plist0, int pl_cap,
+                                                const uint32_t (&n_cand)[FPW], uint32_t (&total)[FPW], const bool (&write)[FPW],
+                                                const size_t (&frame)[FPW], const PeakParamsDev& a, int lane) {
+    const int n = a.n_bins;
+    const int npad = (n + 63) / 64 * 64;
+    const int words = (n + 31) / 32;
+    const int dump = npad / 2 - 1;
+    const float INF = __builtin_huge_valf();
+    uint32_t pre[FPW + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int g = 0; g < FPW; ++g) {
+        pre[g + 1] = pre[g] + n_cand[g];
+        total[g] = 0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    // 2. prominence of each candidate over a PK_PAD-sample window on both sides
-    uint32_t total = 0;
-    for (uint32_t base = 0; base < n_cand; base += 64) {
-        const bool have = base + lane < n_cand;
-        const int i = have ? (int)clist[base + lane] : 0;   // idle lanes sit on the first sample, which is never a peak
+    for (uint32_t base = 0; base < pre[FPW]; base += 64) {
+        const uint32_t p = base + lane;
+        const bool have = p < pre[FPW];
+        int g = 0;
+#pragma unroll
+        for (int q = 1; q < FPW; ++q) g += (p >= pre[q]) ? 1 : 0;
+        uint32_t first = 0;
+#pragma unroll
+        for (int q = 1; q < FPW; ++q) first = (g == q) ? pre[q] : first;
+        const float* x = x0 + g * row;
+        const uint16_t* clist = reinterpret_cast<const uint16_t*>(scratch0 + g * scratch_stride);
+        const int i = have ? (int)clist[p - first] : 0;   // idle lanes sit on the first sample, which is never a peak
         const float xv = x[i];
         const float P = (i <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
         // pL / pR: a sample higher than the peak has been met on that side (later samples no longer count)
@@ -495,22 +525,36 @@ __device__ __forceinline__ bool peaks_wave_lean(const float* x, unsigned char* s
             const int b = __builtin_ctzll(cm);
             cm &= cm - 1;
             const int ci = __builtin_amdgcn_readlane(i, b);
+            const int cg = __builtin_amdgcn_readlane(g, b);
             const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b));
             const float Pc = (ci <= a.highest_bassnote) ? a.bass_min_prominence : a.peak_min_prominence;
+            float v[NK];   // that frame, one bin per lane and chunk (+INF past its end: the sentinels)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) v[k] = ((k << 6) < npad) ? x0[cg * row + (k << 6) + lane] : INF;
             const bool ok = pk_prom_ok_wave<NK>(v, n, ci, h, Pc, lane);
             if (lane == b) peak = ok;
         }
-        const unsigned long long pm = __ballot(peak);
-        plist[peak ? (int)total + (int)__popcll(pm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
+        // peak lists and masks, frame by frame
+        uint32_t slot = (uint32_t)dump;
+#pragma unroll
+        for (int q = 0; q < FPW; ++q) {
+            const unsigned long long pm = __ballot(peak && g == q);
+            if (peak && g == q) slot = total[q] + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            total[q] += __popcll(pm);
+        }
+        plist0[g * pl_cap + (int)slot] = (uint16_t)i;
+        uint32_t* maskw = reinterpret_cast<uint32_t*>(scratch0 + g * scratch_stride + npad);
         __hip_atomic_fetch_or(&maskw[i >> 5], peak ? (1u << (i & 31)) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        total += __popcll(pm);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (a.mask && lane < words) a.mask[frame * words + lane] = maskw[lane];
-    if (a.count && lane == 0) a.count[frame] = total;
-    n_peaks = total;
-    return true;
+#pragma unroll
+    for (int g = 0; g < FPW; ++g) {
+        if (!write[g]) continue;   // uniform
+        const uint32_t* maskw = reinterpret_cast<const uint32_t*>(scratch0 + g * scratch_stride + npad);
+        if (a.mask && lane < words) a.mask[frame[g] * words + lane] = maskw[lane];
+        if (a.count && lane == 0) a.count[frame[g]] = total[g];
+    }
 }
 
 }  // namespace pvq

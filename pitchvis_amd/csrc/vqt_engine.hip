@@ -426,7 +426,7 @@ __host__ __device__ inline size_t peaks_lean_lds_bytes(int n_bins, int dist, int
     const size_t PK_FPG = (size_t)PK_WAVES * PK_FPW;
     const size_t npad = (size_t)((n_bins + 63) / 64 * 64);
     return PK_FPG * sizeof(float) * (npad + 2 * PK_PAD)          // frames, +INF sentinels on both sides
-           + PK_WAVES * peaks_lean_scratch_bytes(n_bins, dist)   // per-wave scratch of the peak search
+           + PK_FPG * peaks_lean_scratch_bytes(n_bins, dist)     // per-frame scratch of the peak search
            + 2 * PK_FPG * npad                                   // peak lists: npad / 2 u16 per frame
            + ((2 * PK_FPG * (size_t)peaks_bass_cap(n_bins, highest_bassnote) + 3) & ~(size_t)3)   // pooled bass list: u16 (frame << 10 | slot)
            + 2 * PK_FPG * sizeof(uint32_t) + 16;                 // per-frame peak counts, bass counter
@@ -442,8 +442,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     const int npad = (n + 63) / 64 * 64;
     const int row = npad + 2 * PK_PAD;
     float* rows = reinterpret_cast<float*>(pk_smem);                                   // [PK_FPG][row]
-    unsigned char* scratch = pk_smem + PK_FPG * sizeof(float) * row + wv * peaks_lean_scratch_bytes(n, a.dist);
-    uint16_t* plists = reinterpret_cast<uint16_t*>(pk_smem + PK_FPG * sizeof(float) * row + PK_WAVES * peaks_lean_scratch_bytes(n, a.dist));
+    const int sb = (int)peaks_lean_scratch_bytes(n, a.dist);                           // scratch of one frame
+    unsigned char* scratch0 = pk_smem + PK_FPG * sizeof(float) * row;                  // [PK_FPG][sb]
+    uint16_t* plists = reinterpret_cast<uint16_t*>(scratch0 + PK_FPG * sb);
     const int pl_cap = npad / 2;                                                       // peaks are never adjacent
     uint16_t* bass = plists + PK_FPG * pl_cap;                                         // [PK_FPG * bass_cap]
     const int bass_cap = peaks_bass_cap(n, a.highest_bassnote);
@@ -457,25 +458,32 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     }
     for (int base = blockIdx.x * PK_FPG; base < n_frames; base += gridDim.x * PK_FPG) {
         if (tid == 0) *n_bass = 0;
-        // 1. peak search: each wave its PK_FPW frames
+        // 1. peak search: each wave scans its PK_FPW frames one after the other, then walks their candidates side by side
+        uint32_t n_cand[PK_FPW], np[PK_FPW];
+        bool done[PK_FPW];
+        size_t frames[PK_FPW];
+#pragma unroll
         for (int g = 0; g < PK_FPW; ++g) {
             const int fi = wv * PK_FPW + g;
             const int frame = base + fi;
-            uint32_t np = 0;
+            n_cand[g] = 0;
+            done[g] = false;
+            frames[g] = (size_t)frame;
             if (frame < n_frames) {
                 float* x = rows + fi * row + PK_PAD;
                 const float* src = db + (size_t)frame * n;
                 for (int i = lane; i < n; i += 64) x[i] = src[i];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool done = peaks_wave_lean<NK, DISTANCE>(x, scratch, plists + fi * pl_cap, np, (size_t)frame, a, lane);
-                if (lane == 0) redo[frame] = done ? 0 : 1;
-                if (!done) np = 0;   // the generic kernel produces this frame's outputs, the continuous ones included
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                done[g] = peaks_lean_scan<NK, DISTANCE>(x, scratch0 + fi * sb, n_cand[g], a, lane);
+                if (lane == 0) redo[frame] = done[g] ? 0 : 1;   // the generic kernel produces that frame's outputs, the continuous ones included
             }
-            if (lane == 0) counts[fi] = np < a.max_peaks ? np : a.max_peaks;
         }
+        peaks_lean_walk<NK, PK_FPW>(rows + wv * PK_FPW * row + PK_PAD, row, scratch0 + wv * PK_FPW * sb, sb, plists + wv * PK_FPW * pl_cap, pl_cap,
+                                    n_cand, np, done, frames, a, lane);
+#pragma unroll
+        for (int g = 0; g < PK_FPW; ++g)
+            if (lane == 0) counts[wv * PK_FPW + g] = np[g] < a.max_peaks ? np[g] : a.max_peaks;
         if (!a.center) continue;   // uniform: mask / count only
         __syncthreads();
         // 2. enhance_peaks_continuous over the pooled peaks, one lane each; bass peaks are handed to step 3
