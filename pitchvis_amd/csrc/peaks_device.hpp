@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace pvq {
 
@@ -387,10 +388,45 @@ __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist)
 // range tests that the +INF sentinels around the frame already decide are left out, and the peak mask is gathered with one
 // LDS atomic per pass — every `if (lane-dependent) store` costs an exec-mask save / branch / restore on the scalar unit, which
 // was as busy as the vector unit here.
+// number of set bits of a ballot below this lane, plus `add`: the two v_mbcnt instructions made for it
+__device__ __forceinline__ int pk_rank(unsigned long long bm, int add) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, (unsigned)add));
+}
+
+// wave-wide minimum by DPP, returned uniform (readlane of the last lane): quads, half rows, rows, then row_bcast across rows.
+// (__shfl_xor costs an address computation and an LDS crossbar round trip per step: 50 vector instructions per frame)
+__device__ __forceinline__ float pk_wave_min(float v) {
+#define PK_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (x)), __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
+    v = fminf(v, PK_DPP(v, 0xB1, 0xf));    // quad_perm(1,0,3,2)
+    v = fminf(v, PK_DPP(v, 0x4E, 0xf));    // quad_perm(2,3,0,1)
+    v = fminf(v, PK_DPP(v, 0x141, 0xf));   // row_half_mirror
+    v = fminf(v, PK_DPP(v, 0x140, 0xf));   // row_mirror: every lane holds its row's minimum
+    v = fminf(v, PK_DPP(v, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
+    v = fminf(v, PK_DPP(v, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's minimum
+#undef PK_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Per-bin thresholds of the candidate test, lane-constant, kept in LDS (thrH[npad], thrP[npad], filled once per workgroup by
+// peaks_lean_thresholds): in registers they are either 2 NK values per lane or — what the compiler makes of the loop-invariant
+// comparisons — 64-bit lane masks per chunk and condition that spill from the scalar file; an LDS read costs the busy vector unit nothing.
+__device__ __forceinline__ void peaks_lean_thresholds(float* thrH, float* thrP, const PeakParamsDev& a, int tid, int n_threads) {
+    const int n = a.n_bins;
+    const int npad = (n + 63) / 64 * 64;
+    for (int i = tid; i < npad; i += n_threads) {
+        const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
+        const float H = bass ? a.bass_min_height : a.peak_min_height;
+        const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
+        thrH[i] = (i >= a.min_bin && i < n) ? H : __builtin_huge_valf();
+        thrP[i] = (P > 0.0f) ? P : -__builtin_huge_valf();   // no prominence bound: every difference passes
+    }
+}
+
 // Part 1 (one frame): peak positions, the distance rule, and the frame's candidates compacted into its clist; n_cand receives
 // their number.  Returns false, with n_cand = 0, when the frame goes to the generic routine.
 template <int NK, bool DISTANCE>   // DISTANCE: min_distance > 1 (84 bins per octave)
-__device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* scratch, uint32_t& n_cand_out, const PeakParamsDev& a, int lane) {
+__device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* scratch, const float* thrH, const float* thrP, uint32_t& n_cand_out,
+                                                const PeakParamsDev& a, int lane) {
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
     const int dump = npad / 2 - 1;
@@ -398,64 +434,87 @@ __device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* s
     uint16_t* clist = reinterpret_cast<uint16_t*>(scratch);          // candidates (strict local maxima past the cheap tests), ascending
     uint32_t* maskw = reinterpret_cast<uint32_t*>(scratch + npad);   // the frame's peak mask, one word per lane
     uint8_t* keep0 = scratch + npad + 256;                           // dist > 1 only: survivors of the distance rule (evaluated at the lower height threshold)
-    float v[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) v[k] = INF;
+    float vt[NK];   // the bin's value where it is a peak position (strict local maximum or second sample of a two-sample plateau), -INF elsewhere
     float fmin_ = INF;
     bool plateau = false;
     const float hmin = fminf(a.bass_min_height, a.peak_min_height);
     int n_dl = 0;
-    uint32_t topm = 0;   // bit k: this lane's bin of chunk k is a peak position (strict local maximum or second sample of a two-sample plateau)
-    static_assert(NK <= 32, "one bit per chunk");
     maskw[lane] = 0;
+    // Without two equal neighbours anywhere in the frame (white noise: all but a few frames in 10^5; frames floored by
+    // power_to_db do have them) a peak position is simply a rise before and a fall after: the first pass assumes that and
+    // notes whether any bin equals its right neighbour; if one does the loop runs again with the full plateau logic.
+    bool tie = false;
+    constexpr bool SHORT = NK <= 12;   // beyond 768 bins a second copy of the unrolled loop and the LDS thresholds cost more than they save (measured: +18 % at 840 bins)
+    auto scan = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        n_dl = 0;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        if ((k << 6) >= n) break;
-        const int i = (k << 6) + lane;
-        const float xv = x[i], l2 = x[i - 2], l = x[i - 1], r = x[i + 1], r2 = x[i + 2];   // +INF outside the frame
-        v[k] = xv;
-        fmin_ = fminf(fmin_, xv);
-        // a rise followed by two equal samples may start a plateau peak of three or more: leave those frames to the
-        // generic code (two-sample plateaus — exact ties of neighbouring bins, a few per 10^5 noise frames — are taken
-        // here: their middle_position is the second sample).  (i < n - 2: the sentinels equal each other)
-        plateau |= (i < n - 2) & (l < xv) & (r == xv) & (r2 == xv);
-        // peak position (pk_is_top): a fall after, and a rise before or a two-sample plateau ending here; the sentinels make the
-        // frame's first and last sample, and everything past them, fail by themselves
-        const bool top = (r < xv) & ((l < xv) | ((l == xv) & (l2 < xv)));
-        topm |= top ? (1u << k) : 0u;
-        if (DISTANCE) {   // the distance rule's candidates (peak positions at or above the lower height threshold), compacted on the way
-            const bool c = top & (xv >= hmin);
-            keep0[i] = c ? 2 : 0;
-            const unsigned long long bm = __ballot(c);
-            clist[c ? n_dl + (int)__popcll(bm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
-            n_dl += __popcll(bm);
+        for (int k = 0; k < NK; ++k) {
+            vt[k] = -INF;
+            if ((k << 6) >= n) continue;
+            const int i = (k << 6) + lane;
+            const float xv = x[i], l = x[i - 1], r = x[i + 1];   // +INF outside the frame
+            bool top = (r < xv) & (l < xv);
+            if (FULL && !SHORT) fmin_ = fminf(fmin_, xv);
+            if (!FULL) {
+                fmin_ = fminf(fmin_, xv);
+                if ((k << 6) + 64 > n) tie |= (r == xv) & (i < n - 1);   // (uniform; past the frame's end the sentinels equal each other)
+                else tie |= r == xv;
+            } else {
+                const float l2 = x[i - 2], r2 = x[i + 2];
+                // a rise followed by two equal samples may start a plateau peak of three or more: leave those frames to the
+                // generic code (two-sample plateaus — exact ties of neighbouring bins — are taken here: their middle_position
+                // is the second sample).  (i < n - 2: the sentinels equal each other)
+                plateau |= (i < n - 2) & (l < xv) & (r == xv) & (r2 == xv);
+                // peak position (pk_is_top): a fall after, and a rise before or a two-sample plateau ending here; the sentinels
+                // make the frame's first and last sample, and everything past them, fail by themselves
+                top = (r < xv) & ((l < xv) | ((l == xv) & (l2 < xv)));
+            }
+            vt[k] = top ? xv : -INF;
+            if (DISTANCE) {   // the distance rule's candidates (peak positions at or above the lower height threshold), compacted on the way
+                const bool c = vt[k] >= hmin;
+                keep0[i] = c ? 2 : 0;
+                const unsigned long long bm = __ballot(c);
+                clist[c ? pk_rank(bm, n_dl) : dump] = (uint16_t)i;
+                n_dl += __popcll(bm);
+            }
         }
+    };
+    if (SHORT) {
+        scan(std::false_type{});
+        if (__ballot(tie)) scan(std::true_type{});
+    } else {
+        scan(std::true_type{});
     }
     n_cand_out = 0;
     if (__ballot(plateau)) return false;
     if (DISTANCE)   // find_peaks' distance rule runs before its prominence test, once per height threshold: one evaluation at the
                     // lower threshold serves both (see peaks_wave_nk); clist is free again from step 1 on
         pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, o));
+    fmin_ = pk_wave_min(fmin_);
 
-    // 1. candidates of the whole frame, compacted: the window walk below then runs once per 64 candidates
-    //    instead of once per 64 bins (a third of the bins are local maxima, far fewer pass height / range)
+    // 1. candidates of the whole frame, compacted: the window walk then runs once per 64 candidates instead of once per 64
+    //    bins (a third of the bins are local maxima, far fewer pass height / range): peak position, min_bin, height, and the
+    //    prominence the frame's minimum allows at all (analysis.rs:332-349 picks the bass or the general pair by bin)
     uint32_t n_cand = 0;
-    const bool noPb = !(a.bass_min_prominence > 0.0f), noPg = !(a.peak_min_prominence > 0.0f);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         if ((k << 6) >= n) break;
         const int i = (k << 6) + lane;
-        const float xv = v[k];
-        const bool bass = i <= a.highest_bassnote;  // analysis.rs:338,346
-        const float H = bass ? a.bass_min_height : a.peak_min_height;
-        const float P = bass ? a.bass_min_prominence : a.peak_min_prominence;
-        const bool noP = bass ? noPb : noPg;
-        bool pre = (i >= a.min_bin) & (((topm >> k) & 1u) != 0) & (xv >= H) & (noP | (xv - fmin_ >= P));
+        float H, P;
+        if (SHORT) {
+            H = thrH[i];
+            P = thrP[i];
+        } else {
+            const bool bass = i <= a.highest_bassnote;
+            H = (i >= a.min_bin) ? (bass ? a.bass_min_height : a.peak_min_height) : INF;
+            const float Pq = bass ? a.bass_min_prominence : a.peak_min_prominence;
+            P = (Pq > 0.0f) ? Pq : -INF;
+        }
+        bool pre = (vt[k] >= H) & (vt[k] - fmin_ >= P);
         if (DISTANCE) pre &= keep0[i] != 0;
         const unsigned long long bm = __ballot(pre);
-        clist[pre ? (int)n_cand + (int)__popcll(bm & ((1ull << lane) - 1ull)) : dump] = (uint16_t)i;
+        clist[pre ? pk_rank(bm, (int)n_cand) : dump] = (uint16_t)i;
         n_cand += __popcll(bm);
     }
     n_cand_out = n_cand;
@@ -539,7 +598,7 @@ __device__ __forceinline__ void peaks_lean_walk(const float* x0, int row, unsign
 #pragma unroll
         for (int q = 0; q < FPW; ++q) {
             const unsigned long long pm = __ballot(peak && g == q);
-            if (peak && g == q) slot = total[q] + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            if (peak && g == q) slot = (uint32_t)pk_rank(pm, (int)total[q]);
             total[q] += __popcll(pm);
         }
         plist0[g * pl_cap + (int)slot] = (uint16_t)i;

@@ -429,7 +429,8 @@ __host__ __device__ inline size_t peaks_lean_lds_bytes(int n_bins, int dist, int
            + PK_FPG * peaks_lean_scratch_bytes(n_bins, dist)     // per-frame scratch of the peak search
            + 2 * PK_FPG * npad                                   // peak lists: npad / 2 u16 per frame
            + ((2 * PK_FPG * (size_t)peaks_bass_cap(n_bins, highest_bassnote) + 3) & ~(size_t)3)   // pooled bass list: u16 (frame << 10 | slot)
-           + 2 * PK_FPG * sizeof(uint32_t) + 16;                 // per-frame peak counts, bass counter
+           + 2 * PK_FPG * sizeof(uint32_t) + 16                  // per-frame peak counts, bass counter
+           + (n_bins <= 768 ? 2 * npad * sizeof(float) : 0);     // thresholds of the candidate test (NK <= 12)
 }
 
 template <int NK, bool DISTANCE, int PK_FPW>
@@ -450,6 +451,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     const int bass_cap = peaks_bass_cap(n, a.highest_bassnote);
     uint32_t* counts = reinterpret_cast<uint32_t*>(pk_smem + ((reinterpret_cast<unsigned char*>(bass + PK_FPG * bass_cap) - pk_smem + 3) & ~(size_t)3));   // [PK_FPG]
     uint32_t* n_bass = counts + PK_FPG;
+    float* thrH = reinterpret_cast<float*>(n_bass + 1);                                // [npad] per-bin height / prominence thresholds of the candidate test
+    float* thrP = thrH + npad;
+    if (NK <= 12) {   // (beyond 768 bins peaks_lean_scan computes them on the fly)
+        peaks_lean_thresholds(thrH, thrP, a, tid, PK_WAVES * 64);
+        __syncthreads();
+    }
     // sentinels of this wave's rows
     for (int g = 0; g < PK_FPW; ++g) {
         float* xs = rows + (wv * PK_FPW + g) * row;
@@ -472,10 +479,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
             if (frame < n_frames) {
                 float* x = rows + fi * row + PK_PAD;
                 const float* src = db + (size_t)frame * n;
-                for (int i = lane; i < n; i += 64) x[i] = src[i];
+                if (NK <= 12) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {   // the frame into its row (the tail of its last 64 stays +INF)
+                        if ((k << 6) >= n) break;
+                        const int i = (k << 6) + lane;
+                        const float t = src[i < n ? i : n - 1];
+                        x[i] = i < n ? t : __builtin_huge_valf();
+                    }
+                } else {
+                    for (int i = lane; i < n; i += 64) x[i] = src[i];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                done[g] = peaks_lean_scan<NK, DISTANCE>(x, scratch0 + fi * sb, n_cand[g], a, lane);
+                done[g] = peaks_lean_scan<NK, DISTANCE>(x, scratch0 + fi * sb, thrH, thrP, n_cand[g], a, lane);
                 if (lane == 0) redo[frame] = done[g] ? 0 : 1;   // the generic kernel produces that frame's outputs, the continuous ones included
             }
         }
