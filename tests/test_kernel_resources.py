@@ -34,6 +34,31 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
         return hits
 
     for u in find("blockdft_gemm_treeILi256") + find("blockdft_gemm_treeILi128") + find("blockdft_gemm_tree_bf16x3ILi256"):
-        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # two 512-thread workgroups per CU
+        # two 512-thread workgroups per CU; a dword or two of the tile set-up may spill, nothing between the matrix instructions may
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] <= 16, u
+    asm = tmp_path / "x.s"
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(asm)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    body, inside = {}, None
+    for line in asm.read_text().splitlines():
+        m = re.match(r"(_ZN3pvq\w+):", line)
+        if m:
+            inside = m.group(1)
+            body[inside] = []
+        elif line.startswith(".Lfunc_end"):
+            inside = None
+        elif inside:
+            body[inside].append(line)
+    checked = 0
+    for name, lines in body.items():
+        if "blockdft_gemm_tree" not in name:
+            continue
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        sc = [i for i, l in enumerate(lines) if re.match(r"\s+scratch_", l)]
+        assert mf, name
+        assert all(i < mf[0] or i > mf[-1] for i in sc), (name, "scratch access inside the K loop", [lines[i] for i in sc])
+        checked += 1
+    assert checked >= 3
     for u in find("blockdft_banddots8_dbILi8ELi4ELi260"):
         assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # 8 waves x 2 workgroups per CU
