@@ -110,6 +110,7 @@ struct BlockDftTables {
     struct TileList {
         int4* d = nullptr; size_t cap = 0;
         int nf = -1, bm = 0, blocks = 0;
+        int cols = 32;   // tile width the list was built for
         int real = 0;   // entries that are tiles (the rest pads the eight per-XCD queues to one length)
     } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
     int tile_list_next = 0;
@@ -119,6 +120,7 @@ struct BlockDftTables {
     bool f2_ok = false;   // the one-kernel form applies (hop 256, windows of <= 64 blocks, every group colours with 8 waves)
     bool t2_ok = false;   // the pipelined GEMM + tree applies (hop 256, windows of <= 64 blocks)
     float4* d_E16 = nullptr;
+    float4* d_E16h = nullptr;      // E in the B-operand order of the 16-column-tile kernel
     int4* d_f2_segs = nullptr;
     float2* d_f2_B = nullptr;
     std::vector<int4> h_f2_segs;
@@ -153,6 +155,7 @@ void free_blockdft_tables(BlockDftTables* t) {
         if (tl.d) (void)hipFree(tl.d);
     if (t->d_clk) (void)hipFree(t->d_clk);
     if (t->d_E16) (void)hipFree(t->d_E16);
+    if (t->d_E16h) (void)hipFree(t->d_E16h);
     if (t->d_f2_segs) (void)hipFree(t->d_f2_segs);
     if (t->d_f2_B) (void)hipFree(t->d_f2_B);
     for (auto& ul : t->f2_units)
@@ -213,6 +216,7 @@ struct GemmTreeArgs {
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
     const float4* E16;        // [column tile][k < K / 2][n < 16]: (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}): B operands of the 16x16x4 fp32 form
+    const float4* E16h;       // 16-column tiles (vqt_gemm_tree16.hpp): [16-column tile][k group g = 2 G + h][lane 64][2]: (cos, -sin) of rows 32 G + 8 kq + 4 h + t, t = 0..3, column lane & 15
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
     unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader clock, 100 MHz clock) before and after its K loop
 };
@@ -481,47 +485,118 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
 // group (16 mirrored sample pairs) takes sample 4 kq + t of every lane; B operand of lane (n, kq): row 16 g + 4 kq + t of the
 // E slice, (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}) as one 16-byte LDS read.  Operands double-buffered, one k group ahead.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-template <bool VEC, int BM>
+template <int BM>   // tiles that lie wholly inside the stream (all but a handful per launch)
 __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
                                                   f32x4a (&accR)[2][2], f32x4a (&accI)[2][2]) {
     constexpr int THREADS = 2 * BM;
+    constexpr bool VEC = true;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
     const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const int K2 = a.K / 2;
+    // A load step fetches a DOUBLE k group (32 mirrored sample pairs): lane (row, kq) takes the 8 consecutive samples 32 G + 8 kq ...
+    // of its row and the 8 mirrored ones, two 16-byte loads each, issued back to back — the four lanes of a row read one whole
+    // 128-byte line at a time.  Fetched 16 pairs at a time (one 64-byte half line per step, the other half a step later) every line
+    // crossed the L2 -> L1 path twice: by then the CU's other waves had pushed it out of the L1 again, and the K loop ran at the
+    // L2's 64-66 GB/s per CU, not at the matrix pipe's rate.  MFMA t of half h of double group G takes sample
+    // 32 G + 8 kq + 4 h + t of every lane; the B rows follow that order.
+    long long jf0[2], jb0[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
+        jf0[mt] = row_lo + 8 * kq;
+        jb0[mt] = row_lo + a.K - 8 - 8 * kq;
+    }
+    float fr[2][2][8], bk[2][2][8];
+    auto load_dgroup = [&](int buf, int G) {   // G: double k group of the whole depth
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (VEC) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jf0[mt] * 4u + 128u * (unsigned)G + 16u * h), 0, 0);
+                    const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jb0[mt] * 4u - 128u * (unsigned)G + 16u * h), 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        fr[buf][mt][4 * h + t] = v[t];
+                        bk[buf][mt][4 * h + t] = w[t];
+                    }
+                }
+            }
+        }
+    };
+    float4* El = reinterpret_cast<float4*>(smem);   // [rows][16]
+    auto mfma_half = [&](int buf, int Gl, int h) {  // Gl: double group inside the staged slice
+        const float4* e = El + (32 * Gl + 8 * kq + 4 * h) * 16 + m16;
+        float4 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = e[t * 16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float sm = fr[buf][mt][4 * h + t] + bk[buf][mt][7 - 4 * h - t];
+                const float df = fr[buf][mt][4 * h + t] - bk[buf][mt][7 - 4 * h - t];
+                accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].x, accR[mt][0], 0, 0, 0);
+                accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].y, accR[mt][1], 0, 0, 0);
+                accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].z, accI[mt][0], 0, 0, 0);
+                accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].w, accI[mt][1], 0, 0, 0);
+            }
+        }
+    };
+    const int nG = K2 / 32;   // (K2 is a multiple of 32: the fused path takes hops that are multiples of 64)
+    load_dgroup(0, 0);
+    for (int kc = 0; kc < K2; kc += FR_KC) {
+        const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
+        if (kc > 0) __syncthreads();   // every wave is done with the previous slice
+        for (int i = tid; i < rows * 16; i += THREADS) El[i] = e_tile[(size_t)kc * 16 + i];
+        __syncthreads();
+        const int ng = rows / 32, G0 = kc / 32;
+        for (int Gl = 0; Gl < ng; Gl += 2) {   // two double groups per pass: buffer indices stay compile-time
+            if (G0 + Gl + 1 < nG) load_dgroup(1, G0 + Gl + 1);
+            mfma_half(0, Gl, 0);
+            mfma_half(0, Gl, 1);
+            if (Gl + 1 >= ng) break;           // (a 32-row slice: hop 64)
+            if (G0 + Gl + 2 < nG) load_dgroup(0, G0 + Gl + 2);
+            mfma_half(1, Gl + 1, 0);
+            mfma_half(1, Gl + 1, 1);
+        }
+    }
+}
+
+// The same loop for the tiles that touch the stream's start or end (dword loads, each range-checked by the buffer hardware;
+// samples before the stream get an explicit out-of-range offset, see fused_f32_stage_load): same MFMAs on the same samples in
+// the same order — k group g = 2 G + h — but one 16-pair half of a double group per load step, which keeps its 32 dword loads
+// per step inside the register budget.
+template <int BM>
+__device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
+                                                       f32x4a (&accR)[2][2], f32x4a (&accI)[2][2]) {
+    constexpr int THREADS = 2 * BM;
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
     const int K2 = a.K / 2;
     long long jf0[2], jb0[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
-        jf0[mt] = row_lo + 4 * kq;
-        jb0[mt] = row_lo + a.K - 4 - 4 * kq;
+        jf0[mt] = row_lo + 8 * kq;
+        jb0[mt] = row_lo + a.K - 4 - 8 * kq;
     }
     float fr[2][2][4], bk[2][2][4];
-    auto load_group = [&](int buf, int g) {   // g: k group of the whole depth (16 sample pairs each)
+    auto load_group = [&](int buf, int g) {
+        const int so = 32 * (g >> 1) + 4 * (g & 1);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            if (VEC) {
-                const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jf0[mt] * 4u + 64u * (unsigned)g), 0, 0);
-                const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jb0[mt] * 4u - 64u * (unsigned)g), 0, 0);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    fr[buf][mt][t] = v[t];
-                    bk[buf][mt][t] = w[t];
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const long long xf = jf0[mt] + 16 * g + t, xb = jb0[mt] - 16 * g + t;
-                    fr[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xf >= 0 ? (unsigned)(xf * 4ll) : 0xFFFFFFFCu, 0, 0));
-                    bk[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xb >= 0 ? (unsigned)(xb * 4ll) : 0xFFFFFFFCu, 0, 0));
-                }
+            for (int t = 0; t < 4; ++t) {
+                const long long xf = jf0[mt] + so + t, xb = jb0[mt] - so + t;
+                fr[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xf >= 0 ? (unsigned)(xf * 4ll) : 0xFFFFFFFCu, 0, 0));
+                bk[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xb >= 0 ? (unsigned)(xb * 4ll) : 0xFFFFFFFCu, 0, 0));
             }
-        }
     };
     float4* El = reinterpret_cast<float4*>(smem);   // [rows][16]
     auto mfma_group = [&](int buf, int gl) {        // gl: k group inside the staged slice
-        const float4* e = El + (16 * gl + 4 * kq) * 16 + m16;
+        const float4* e = El + (32 * (gl >> 1) + 8 * kq + 4 * (gl & 1)) * 16 + m16;
         float4 b[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[t] = e[t * 16];
@@ -586,9 +661,9 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
         a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
     if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
-        fused_f32_kloop16<true, BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
+        fused_f32_kloop16<BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
     else
-        fused_f32_kloop16<false, BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
+        fused_f32_kloop16_edge<BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -1439,6 +1514,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
 }  // namespace pvq
 #include "vqt_fused2.hpp"
 #include "vqt_gemm_tree2.hpp"
+#include "vqt_gemm_tree16.hpp"
 namespace pvq {
 
 // ------------------------------------------------------------------------------------------------
@@ -1809,6 +1885,27 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                     E16[((size_t)tt * K2 + m) * 16 + n] = make_float4(e[2 * n], e[2 * (n + 16)], e[2 * n + 1], e[2 * (n + 16) + 1]);
                 }
     }
+    std::vector<float4> E16h;
+    if (hop % 64 == 0) {   // E in the B-operand order of the 16-column-tile kernel: [16-column tile][k group][lane][2]
+        const size_t K2 = hop / 2, ng = K2 / 16;
+        const int t16n = tile * 2;
+        E16h.resize((size_t)t16n * ng * 128);
+        for (int t16 = 0; t16 < t16n; ++t16)
+            for (size_t g = 0; g < ng; ++g)
+                for (int l = 0; l < 64; ++l) {
+                    const int n = l & 15, kq = l >> 4;
+                    const int col = t16 * 16 + n;                                   // column of the padded 32-column-tile space
+                    float v[8];
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const size_t m = 32 * (g >> 1) + 8 * kq + 4 * (g & 1) + tt;   // the k order of fused_f32_kloop16
+                        const float* e = E.data() + m * ntot + (size_t)(col / CB_C) * GM_BN + 2 * (col % CB_C);
+                        v[2 * tt] = e[0];
+                        v[2 * tt + 1] = e[1];
+                    }
+                    E16h[(((size_t)t16 * ng + g) * 64 + l) * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+                    E16h[(((size_t)t16 * ng + g) * 64 + l) * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+    }
     if (t->t2_ok) {
         // Kernel-product blocks of 8 bins -> waves: a block is open from the column tile of its first column to that of its
         // last; a wave holds one block's sums at a time, so blocks whose tile spans overlap need different waves (interval
@@ -1902,7 +1999,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
               up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
-              up(&t->d_E16, E16) && (!t->t2_ok || (up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
+              up(&t->d_E16, E16) && (E16h.empty() || up(&t->d_E16h, E16h)) && (!t->t2_ok || (up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -2157,14 +2254,19 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             // 256-row tiles for the split-bf16 form: 257 - Nb complete frames per tile (1.08x row recomputation instead
             // of 1.2x) and the E^T planes staged once per 256 rows; measured 7 % faster than 128-row tiles
             const int fused_bm = bm_env != 128 ? 256 : FT_BM;
+            // 16-column tiles (vqt_gemm_tree16.hpp): three workgroups per CU instead of two; fp32 form, 256-row tiles, frame-stripe order
+            static const int tile16_env = getenv("PVQ_TILE16") ? atoi(getenv("PVQ_TILE16")) : 0;   // developer knob while the form is being measured
+            const bool use16 = tile16_env && !use_bf && fused_bm == 256 && hop % 64 == 0 && t->d_E16h != nullptr;
+            const int tile_cols = use16 ? 16 : CB_C;
+            auto col_tiles = [&](const BlockGroup& G) { return use16 ? (G.n_cols + 15) / 16 : G.n_tiles; };
             int off = 0, real_tiles = 0;
             for (int g = 0; g < t->n_groups; ++g) {
                 fa.blk_off[g] = off;
                 const int S = fused_bm - t->groups[g].nb_f + 1;
                 const int rows_g = (int)nf + t->groups[g].nb - t->groups[g].nb_f;
                 const int mt8 = (((rows_g + S - 1) / S) + 7) / 8 * 8;
-                off += t->groups[g].n_tiles * mt8;
-                real_tiles += t->groups[g].n_tiles * ((rows_g + S - 1) / S);
+                off += col_tiles(t->groups[g]) * mt8;
+                real_tiles += col_tiles(t->groups[g]) * ((rows_g + S - 1) / S);
             }
             for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
             // Frame-stripe order (developer knob PVQ_TILE_ORDER=0 keeps the group-major order above): the stream is cut into
@@ -2173,10 +2275,10 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             // then read a stripe's PCM rows from that XCD's L2 while they are resident (once per stripe, not once per group).
             static const int tile_order_env = getenv("PVQ_TILE_ORDER") ? atoi(getenv("PVQ_TILE_ORDER")) : 1;
             fa.tile_list = nullptr;
-            if (tile_order_env) {
+            if (tile_order_env || use16) {
                 BlockDftTables::TileList* tl = nullptr;
                 for (auto& c : t->tile_lists)
-                    if (c.nf == (int)nf && c.bm == fused_bm) tl = &c;
+                    if (c.nf == (int)nf && c.bm == fused_bm && c.cols == tile_cols) tl = &c;
                 if (!tl) {
                     tl = &t->tile_lists[t->tile_list_next];
                     t->tile_list_next ^= 1;
@@ -2188,7 +2290,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                         const int S = fused_bm - G.nb_f + 1;
                         const int rows_g = (int)nf + G.nb - G.nb_f;
                         for (int f0 = 0; f0 < rows_g; f0 += S)
-                            for (int ntl = 0; ntl < G.n_tiles; ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
+                            for (int ntl = 0; ntl < col_tiles(G); ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
                     }
                     size_t L = 0;
                     for (auto& v : q) {
@@ -2208,6 +2310,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     PVQ_HIP(hipMemcpy(tl->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
                     tl->nf = (int)nf;
                     tl->bm = fused_bm;
+                    tl->cols = tile_cols;
                     tl->blocks = (int)list.size();
                     tl->real = 0;
                     for (auto& v : q) tl->real += (int)v.size();
@@ -2220,6 +2323,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.comb_tw = t->d_comb_tw;
             fa.Et = t->d_Et;
             fa.E16 = t->d_E16;
+            fa.E16h = t->d_E16h;
             static const char* stamps_env = getenv("PVQ_STAMPS");   // developer knob: dump per-workgroup phase stamps once
             static bool stamps_done = false;
             const bool do_stamps = stamps_env && !stamps_done;
@@ -2228,7 +2332,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 8 * 8 + 8));
             // flop the GEMM's matrix instructions issue in this launch: tiles x rows x 64 real columns x depth x 2
             // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
-            last_gemm_flop_ = (double)real_tiles * fused_bm * FT_BN * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
+            last_gemm_flop_ = (double)real_tiles * fused_bm * (2 * tile_cols) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
             fa.clk = nullptr;
             if (profiling_ && !use_bf) {
                 const size_t need = ((size_t)off / 64 + 1) * 4 * sizeof(unsigned long long);
@@ -2248,6 +2352,8 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (use_bf)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<128>, dim3(off), dim3(256), 0, stream, fa);
+            else if (use16)
+                hipLaunchKernelGGL(blockdft_gemm_tree16<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
             else

@@ -208,6 +208,49 @@ def test_unfused_fallback_stages_in_a_subprocess():
     assert r.returncode == 0 and "UNFUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_tile16_form_bit_identical_in_a_subprocess():
+    """The opt-in 16-column-tile form of the hop-DFT stage kept for measurement (PVQ_TILE16=1: blockdft_gemm_tree16,
+    three workgroups per CU) computes the same bits as the shipped kernel on every test geometry: same sums, same k order,
+    same tree levels — a column's value must not depend on the width of the tile that produced it.  Child processes: the knob
+    is read once per process."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, os
+        sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+        import numpy as np, torch
+        import pitchvis_amd as P
+        from helpers import GEOMS, get_geom, white_noise
+        out = {}
+        for name in GEOMS:
+            pp, op = get_geom(name)
+            hop = 128 if op.sr > 90000 else 256
+            v = P.Vqt.new(pp, 0)
+            v.set_algo(P.ALGO_BLOCKDFT)
+            nf, n_lead = 1500, 777
+            pcm = torch.from_numpy(white_noise(n_lead + hop * nf, 11)).cuda()
+            cx = torch.zeros((nf, v.n_bins, 2), device="cuda")
+            db = torch.empty((nf, v.n_bins), device="cuda")
+            v.calculate_batch_db_device(pcm, hop, nf, db, n_lead=n_lead, d_out_cplx=cx)
+            torch.cuda.synchronize()
+            out[name + "_db"] = db.cpu().numpy()
+            out[name + "_cx"] = cx.cpu().numpy()
+        np.savez(sys.argv[1], **out)
+        print("FORM_OK")
+    """)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    res = {}
+    for tag, env in (("base", {}), ("tile16", {"PVQ_TILE16": "1"})):
+        f = os.path.join(root, "gpurun_out", f"forms_{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0 and "FORM_OK" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(f))
+        os.remove(f)
+    for tag in ("tile16",):
+        for k, a in res["base"].items():
+            assert np.array_equal(a.view(np.uint32), res[tag][k].view(np.uint32)), (tag, k)
+
+
 @pytest.mark.parametrize("name", ["default_22k_588", "bench_48k_252", "bench_48k_288", "hires_96k_360", "hires_96k_840", "serial_22k_180"])
 def test_same_input_same_output_every_geometry(name):
     """Reference convention: same input => same output.  Three runs of the whole path per geometry and
