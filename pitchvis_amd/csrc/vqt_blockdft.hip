@@ -372,7 +372,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
     }
     PVQ_STAMP(2);
     // lanes walk the frames of one column: 512-byte runs in memory, conflict-free LDS reads
-    const int j = tid & (BM - 1);
+    const int j = tid % BM;   // (BM = 160: not a power of two)
     const int f = t.f0 + j;
     if (j < t.S && f < t.nfr) {
         // windows of more than 64 blocks: 64-block partial sums go to Y, blockdft_tree_finish adds the last levels
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     Pt[wave * 32 + mt * 16 + 4 * kq + r][np * 16 + m16] = make_float2(accR[mt][np][r], accI[mt][np][r]);
-        if (tid < 15 * FT_LDP) Pt[BM][tid] = make_float2(0.0f, 0.0f);   // the spare rows (Pt[BM][..] runs on through them)
+        for (int i = tid; i < 15 * FT_LDP; i += 2 * BM) Pt[BM][i] = make_float2(0.0f, 0.0f);   // the spare rows (Pt[BM][..] runs on through them)
     }
     __syncthreads();
     PVQ_STAMP(5);
@@ -2253,7 +2253,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             static const int bm_env = getenv("PVQ_FUSED_BM") ? atoi(getenv("PVQ_FUSED_BM")) : 0;   // developer knob
             // 256-row tiles for the split-bf16 form: 257 - Nb complete frames per tile (1.08x row recomputation instead
             // of 1.2x) and the E^T planes staged once per 256 rows; measured 7 % faster than 128-row tiles
-            const int fused_bm = bm_env != 128 ? 256 : FT_BM;
+            const int fused_bm = (bm_env == 160 && !use_bf) ? 160 : (bm_env != 128 ? 256 : FT_BM);   // 160: three workgroups per CU (fp32 form)
             // 16-column tiles (vqt_gemm_tree16.hpp): three workgroups per CU instead of two; fp32 form, 256-row tiles, frame-stripe order
             static const int tile16_env = getenv("PVQ_TILE16") ? atoi(getenv("PVQ_TILE16")) : 0;   // developer knob while the form is being measured
             const bool use16 = tile16_env && !use_bf && fused_bm == 256 && hop % 64 == 0 && t->d_E16h != nullptr;
@@ -2356,6 +2356,8 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 hipLaunchKernelGGL(blockdft_gemm_tree16<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
+            else if (fused_bm == 160)
+                hipLaunchKernelGGL(blockdft_gemm_tree<160>, dim3(off), dim3(320), 0, stream, fa);
             else
                 hipLaunchKernelGGL(blockdft_gemm_tree<128>, dim3(off), dim3(256), 0, stream, fa);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
