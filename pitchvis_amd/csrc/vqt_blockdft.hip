@@ -380,8 +380,7 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
 #pragma unroll 4
         for (int cc = tid / BM; cc < CB_C; cc += 2) {   // streamed out (non-temporal): the kernel-product stage that reads X back runs 5 % faster for it
             const float2 val = A[j][cc];
-            __builtin_nontemporal_store(val.x, &dst[cc * 64].x);
-            __builtin_nontemporal_store(val.y, &dst[cc * 64].y);
+            __builtin_nontemporal_store((f32x2){val.x, val.y}, reinterpret_cast<f32x2*>(&dst[cc * 64]));   // one 8-byte store
         }
     }
     if (a.stamps) {

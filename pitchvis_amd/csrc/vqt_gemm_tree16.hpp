@@ -153,8 +153,7 @@ __device__ __forceinline__ void h16_tree_store(float* smem, const float2 (*tw)[H
 #pragma unroll 4
         for (int cc = tid / BM; cc < H16_C; cc += 2) {   // streamed out (non-temporal), as in fused_tree_store
             const float2 val = A[j][cc];
-            __builtin_nontemporal_store(val.x, &dst[cc * 64].x);
-            __builtin_nontemporal_store(val.y, &dst[cc * 64].y);
+            __builtin_nontemporal_store((f32x2){val.x, val.y}, reinterpret_cast<f32x2*>(&dst[cc * 64]));   // one 8-byte store
         }
     }
     if (a.stamps) {
