@@ -84,6 +84,14 @@ uint32_t pvq_vqt_n_bins(const pvq_vqt *v);
 double pvq_vqt_delay_seconds(const pvq_vqt *v);
 /* number of trailing samples of the n_fft buffer that any window group reads (the window union) */
 uint32_t pvq_vqt_window_union(const pvq_vqt *v);
+/* replaces Filter::bandwidth_3db_in_hz (vqt.rs:421, :817-818; find_3db_points / calculate_bandwidth, vqt.rs:956-989):
+ * the -3 dB band of every bin's filter in Hz, read off its decimated frequency response; n_bins floats each */
+pvq_status pvq_vqt_bandwidths_3db(const pvq_vqt *v, float *lo_hz, float *hi_hz);
+/* the warn!() lines of the kernel construction (vqt.rs:695-709: a coverage gap between the -3 dB bands of neighbouring
+ * filters — "decrease quality to close the gap"), in bin order: their number, and line i copied NUL-terminated into buf
+ * (truncated to cap bytes) */
+uint32_t pvq_vqt_warning_count(const pvq_vqt *v);
+pvq_status pvq_vqt_warning(const pvq_vqt *v, uint32_t i, char *buf, size_t cap);
 
 /* replaces Vqt::kernel() (vqt.rs:511-513) -> VqtKernel{window_groups} (vqt.rs:388-415) */
 uint32_t pvq_vqt_n_groups(const pvq_vqt *v);

@@ -211,6 +211,15 @@ class Vqt:
         #: vqt.rs:449 `pub delay: Duration`, in seconds
         self.delay = L.pvq_vqt_delay_seconds(self._h)
         self.window_union = L.pvq_vqt_window_union(self._h)
+        # Filter::bandwidth_3db_in_hz per bin and the kernel construction's coverage-gap warnings (vqt.rs:695-709, :956-989)
+        lo = np.empty(L.pvq_vqt_n_bins(self._h), np.float32); hi = np.empty_like(lo)
+        _check(L.pvq_vqt_bandwidths_3db(self._h, lo.ctypes.data_as(C.POINTER(C.c_float)), hi.ctypes.data_as(C.POINTER(C.c_float))))
+        self.bandwidth_3db_in_hz = (lo, hi)
+        self.warnings = []
+        for i in range(L.pvq_vqt_warning_count(self._h)):
+            buf = C.create_string_buffer(512)
+            _check(L.pvq_vqt_warning(self._h, i, buf, 512))
+            self.warnings.append(buf.value.decode())
 
     @classmethod
     def new(cls, params: VqtParameters, device: Optional[int] = 0) -> "Vqt":

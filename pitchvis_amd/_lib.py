@@ -28,6 +28,7 @@ EXPORTS = [
     "pvq_stream_push", "pvq_stream_gain", "pvq_stream_chunk_size_ms", "pvq_stream_frame_db", "pvq_stream_read",
     "pvq_calculate_color", "pvq_led_frame", "pvq_host_alloc", "pvq_host_free",
     "pvq_vqt_input_status", "pvq_vqt_last_gemm_flop", "pvq_vqt_last_sclk_mhz",
+    "pvq_vqt_bandwidths_3db", "pvq_vqt_warning_count", "pvq_vqt_warning",
 ]
 
 PVQ_OK = 0
@@ -118,6 +119,9 @@ def load():
     L.pvq_vqt_n_bins.argtypes = [vp]; L.pvq_vqt_n_bins.restype = C.c_uint32
     L.pvq_vqt_delay_seconds.argtypes = [vp]; L.pvq_vqt_delay_seconds.restype = C.c_double
     L.pvq_vqt_window_union.argtypes = [vp]; L.pvq_vqt_window_union.restype = C.c_uint32
+    L.pvq_vqt_bandwidths_3db.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]; L.pvq_vqt_bandwidths_3db.restype = C.c_int
+    L.pvq_vqt_warning_count.argtypes = [vp]; L.pvq_vqt_warning_count.restype = C.c_uint32
+    L.pvq_vqt_warning.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]; L.pvq_vqt_warning.restype = C.c_int
     L.pvq_vqt_n_groups.argtypes = [vp]; L.pvq_vqt_n_groups.restype = C.c_uint32
     L.pvq_vqt_group_info.argtypes = [vp, C.c_uint32, up]; L.pvq_vqt_group_info.restype = C.c_int
     L.pvq_vqt_group_csr.argtypes = [vp, C.c_uint32, C.c_int, up, up, fp]; L.pvq_vqt_group_csr.restype = C.c_int

@@ -196,6 +196,35 @@ uint32_t pvq_vqt_window_union(const pvq_vqt* v) {
         return v ? v->impl->plan().window_union : 0;
     } catch (...) { (void)translate_exception(); return 0; }
 }
+pvq_status pvq_vqt_bandwidths_3db(const pvq_vqt* v, float* lo_hz, float* hi_hz) {
+    try {
+        if (!v || !lo_hz || !hi_hz) return null_handle();
+        const pvq::HostPlan& pl = v->impl->plan();
+        std::copy(pl.bandwidth_lo_hz.begin(), pl.bandwidth_lo_hz.end(), lo_hz);
+        std::copy(pl.bandwidth_hi_hz.begin(), pl.bandwidth_hi_hz.end(), hi_hz);
+        return PVQ_OK;
+    } catch (...) { return translate_exception(); }
+}
+uint32_t pvq_vqt_warning_count(const pvq_vqt* v) {
+    try {
+        return v ? (uint32_t)v->impl->plan().warnings.size() : 0;
+    } catch (...) { (void)translate_exception(); return 0; }
+}
+pvq_status pvq_vqt_warning(const pvq_vqt* v, uint32_t i, char* buf, size_t cap) {
+    try {
+        if (!v || !buf || cap == 0) return null_handle();
+        const pvq::HostPlan& pl = v->impl->plan();
+        if (i >= pl.warnings.size()) {
+            pvq::set_last_error("warning index out of range");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        const std::string& w = pl.warnings[i];
+        const size_t nb = std::min(cap - 1, w.size());
+        std::memcpy(buf, w.data(), nb);
+        buf[nb] = '\0';
+        return PVQ_OK;
+    } catch (...) { return translate_exception(); }
+}
 uint32_t pvq_vqt_n_groups(const pvq_vqt* v) {
     try {
         return v ? static_cast<uint32_t>(v->impl->kernel().window_groups.size()) : 0;

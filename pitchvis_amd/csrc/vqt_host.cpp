@@ -95,7 +95,7 @@ struct RateGroup {  // vqt.rs:608-612
 // vqt.rs:769-852: one filter's sparsified conjugate spectrum at its decimated rate.
 void calculate_filter(float sr, float sparsity_quantile, uint32_t sr_scaling, const FilterParams& fp,
                       uint32_t w0, uint32_t w1, float window_center, const SmallFft& fft,
-                      std::vector<cf32>& v) {
+                      std::vector<cf32>& v, float& band_lo_hz, float& band_hi_hz) {
     const float scaling = static_cast<float>(sr_scaling);
     const float scaled_freq = fp.freq * scaling;
     const float scaled_window_length = fp.window_length / scaling;
@@ -134,6 +134,18 @@ void calculate_filter(float sr, float sparsity_quantile, uint32_t sr_scaling, co
 
     std::vector<float> mags(scaled_n_fft);
     for (uint32_t i = 0; i < scaled_n_fft; ++i) mags[i] = std::hypot(v[i].re, v[i].im);
+    {   // calculate_bandwidth (vqt.rs:981-989) over find_3db_points (vqt.rs:962-977), at the decimated rate
+        uint32_t peak = 0;   // util::arg_max: the first maximum
+        for (uint32_t i = 1; i < scaled_n_fft; ++i)
+            if (mags[i] > mags[peak]) peak = i;
+        const float threshold = mags[peak] / std::sqrt(2.0f);   // -3 dB
+        uint32_t lower = peak, upper = peak;
+        while (lower > 0 && mags[lower] > threshold) --lower;
+        while (upper < scaled_n_fft - 1 && mags[upper] > threshold) ++upper;
+        const float scaled_sr = sr / scaling;
+        band_lo_hz = static_cast<float>(lower) * scaled_sr / static_cast<float>(scaled_n_fft);
+        band_hi_hz = static_cast<float>(upper) * scaled_sr / static_cast<float>(scaled_n_fft);
+    }
     std::sort(mags.begin(), mags.end());
     float total = 0.0f;
     for (float m : mags) total += m;
@@ -255,6 +267,10 @@ VqtError build_plan(const VqtParameters& p, HostPlan& plan) {
     const float kernel_gain = std::sqrt(p.sr);
     uint32_t min_begin = p.n_fft;
     std::vector<cf32> spectrum;
+    float last_upper_bandwidth = 0.0f;   // vqt.rs:649
+    plan.bandwidth_lo_hz.assign(filters.size(), 0.0f);
+    plan.bandwidth_hi_hz.assign(filters.size(), 0.0f);
+    plan.warnings.clear();
     for (size_t a = 0; a < rate_groups.size();) {
         size_t b = a + 1;
         while (b < rate_groups.size() && rate_groups[b].w0 == rate_groups[a].w0 && rate_groups[b].w1 == rate_groups[a].w1) ++b;
@@ -274,8 +290,20 @@ VqtError build_plan(const VqtParameters& p, HostPlan& plan) {
             const uint32_t scaled_n_fft = window_size / m;
             const SmallFft fft(scaled_n_fft);
             for (uint32_t f = 0; f < rate_groups[i].count; ++f, ++row) {
-                calculate_filter(p.sr, p.sparsity_quantile, m, filters[rate_groups[i].first + f], wg.window_begin,
-                                 wg.window_end, window_center, fft, spectrum);
+                const FilterParams& fpar = filters[rate_groups[i].first + f];
+                float blo = 0.0f, bhi = 0.0f;
+                calculate_filter(p.sr, p.sparsity_quantile, m, fpar, wg.window_begin, wg.window_end, window_center, fft, spectrum, blo, bhi);
+                plan.bandwidth_lo_hz[rate_groups[i].first + f] = blo;
+                plan.bandwidth_hi_hz[rate_groups[i].first + f] = bhi;
+                if (last_upper_bandwidth > 0.0f && blo > last_upper_bandwidth) {   // vqt.rs:695-709, the reference's warn!() text
+                    char msg[320];
+                    std::snprintf(msg, sizeof msg,
+                                  "coverage gap below the filter at %.1f Hz: its -3 dB band starts at %.2f Hz but the previous filter's band ends at "
+                                  "%.2f Hz (%.1f%% of this filter's bandwidth); decrease quality to close the gap",
+                                  fpar.freq, blo, last_upper_bandwidth, 100.0f * (blo - last_upper_bandwidth) / (bhi - blo));
+                    plan.warnings.emplace_back(msg);
+                }
+                last_upper_bandwidth = bhi;
                 for (uint32_t j = 0; j < scaled_n_fft; ++j) {
                     const cf32 z = spectrum[j];
                     if (z.re == 0.0f && z.im == 0.0f) continue;

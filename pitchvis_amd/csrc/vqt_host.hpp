@@ -87,6 +87,11 @@ struct HostPlan {
     float window_center = 0.0f;
     double delay_seconds = 0.0;  // vqt.rs:756
     uint32_t window_union = 0;   // n_fft - min(window_begin)
+    // Filter::bandwidth_3db_in_hz (vqt.rs:421, :817-818): the -3 dB band of every filter, read off its decimated frequency response
+    // (find_3db_points / calculate_bandwidth, vqt.rs:956-989: "a very crude approximation": the response only spans a few buckets)
+    std::vector<float> bandwidth_lo_hz, bandwidth_hi_hz;
+    // the kernel construction's warn!() lines (vqt.rs:695-709: coverage gaps between neighbouring filters), in bin order
+    std::vector<std::string> warnings;
 };
 
 // ln(f_k) per bin exactly as enhance_peaks_continuous evaluates it (peak_detection.rs:81-86):
