@@ -484,7 +484,7 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
 // group (16 mirrored sample pairs) takes sample 4 kq + t of every lane; B operand of lane (n, kq): row 16 g + 4 kq + t of the
 // E slice, (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}) as one 16-byte LDS read.  Operands double-buffered, one k group ahead.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-template <int BM>   // tiles that lie wholly inside the stream (all but a handful per launch)
+template <int BM, bool HALF>   // tiles that lie wholly inside the stream (all but a handful per launch); HALF: at most 16 columns (a group's last tile): the second 16-column half is not computed
 __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
                                                   f32x4a (&accR)[2][2], f32x4a (&accI)[2][2]) {
     constexpr int THREADS = 2 * BM;
@@ -537,9 +537,9 @@ __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* 
                 const float sm = fr[buf][mt][4 * h + t] + bk[buf][mt][7 - 4 * h - t];
                 const float df = fr[buf][mt][4 * h + t] - bk[buf][mt][7 - 4 * h - t];
                 accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].x, accR[mt][0], 0, 0, 0);
-                accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].y, accR[mt][1], 0, 0, 0);
+                if (!HALF) accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].y, accR[mt][1], 0, 0, 0);
                 accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].z, accI[mt][0], 0, 0, 0);
-                accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].w, accI[mt][1], 0, 0, 0);
+                if (!HALF) accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].w, accI[mt][1], 0, 0, 0);
             }
         }
     };
@@ -659,10 +659,14 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
         a.clk[(blockIdx.x >> 6) * 4 + 0] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
-    if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
-        fused_f32_kloop16<BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
-    else
+    // a group's last column tile may hold 16 columns or fewer (3 of the 21 tiles at 48 kHz / 252 bins): half the MFMAs
+    const bool half = T.ntl == T.G.n_tiles - 1 && T.G.n_cols - T.ntl * CB_C <= 16;
+    if (!(tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes))
         fused_f32_kloop16_edge<BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
+    else if (half)
+        fused_f32_kloop16<BM, true>(a, smem, tile_lo, e_tile, tid, accR, accI);
+    else
+        fused_f32_kloop16<BM, false>(a, smem, tile_lo, e_tile, tid, accR, accI);
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -2259,6 +2263,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             const int tile_cols = use16 ? 16 : CB_C;
             auto col_tiles = [&](const BlockGroup& G) { return use16 ? (G.n_cols + 15) / 16 : G.n_tiles; };
             int off = 0, real_tiles = 0;
+            double eff_tiles = 0.0;
             for (int g = 0; g < t->n_groups; ++g) {
                 fa.blk_off[g] = off;
                 const int S = fused_bm - t->groups[g].nb_f + 1;
@@ -2266,6 +2271,10 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 const int mt8 = (((rows_g + S - 1) / S) + 7) / 8 * 8;
                 off += col_tiles(t->groups[g]) * mt8;
                 real_tiles += col_tiles(t->groups[g]) * ((rows_g + S - 1) / S);
+                // matrix work in whole-tile units: a last tile of at most 16 columns runs half the MFMAs (fp32 32-column kernel; the few
+                // tiles at the stream's ends run the full loop: counted as half all the same)
+                const bool half_last = !use16 && !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
+                eff_tiles += (col_tiles(t->groups[g]) - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
             }
             for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
             // Frame-stripe order (developer knob PVQ_TILE_ORDER=0 keeps the group-major order above): the stream is cut into
@@ -2331,7 +2340,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 8 * 8 + 8));
             // flop the GEMM's matrix instructions issue in this launch: tiles x rows x 64 real columns x depth x 2
             // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
-            last_gemm_flop_ = (double)real_tiles * fused_bm * (2 * tile_cols) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
+            last_gemm_flop_ = eff_tiles * fused_bm * (2 * tile_cols) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
             fa.clk = nullptr;
             if (profiling_ && !use_bf) {
                 const size_t need = ((size_t)off / 64 + 1) * 4 * sizeof(unsigned long long);

@@ -35,7 +35,7 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
 
     for u in find("blockdft_gemm_treeILi256") + find("blockdft_gemm_treeILi128") + find("blockdft_gemm_tree_bf16x3ILi256"):
         # two 512-thread workgroups per CU; a few dwords of the tile set-up (stream-edge variant) may spill, the K loop bodies may not
-        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] <= 32, u
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] <= 48, u
     asm = tmp_path / "x.s"
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(asm)],
                        capture_output=True, text=True, timeout=600)
