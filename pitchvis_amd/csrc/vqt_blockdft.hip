@@ -2262,15 +2262,14 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             const bool use16 = tile16_env && !use_bf && fused_bm == 256 && hop % 64 == 0 && t->d_E16h != nullptr;
             const int tile_cols = use16 ? 16 : CB_C;
             auto col_tiles = [&](const BlockGroup& G) { return use16 ? (G.n_cols + 15) / 16 : G.n_tiles; };
-            int off = 0, real_tiles = 0;
-            double eff_tiles = 0.0;
+            int off = 0;
+            double eff_tiles = 0.0;   // matrix work of the launch in whole-tile units
             for (int g = 0; g < t->n_groups; ++g) {
                 fa.blk_off[g] = off;
                 const int S = fused_bm - t->groups[g].nb_f + 1;
                 const int rows_g = (int)nf + t->groups[g].nb - t->groups[g].nb_f;
                 const int mt8 = (((rows_g + S - 1) / S) + 7) / 8 * 8;
                 off += col_tiles(t->groups[g]) * mt8;
-                real_tiles += col_tiles(t->groups[g]) * ((rows_g + S - 1) / S);
                 // matrix work in whole-tile units: a last tile of at most 16 columns runs half the MFMAs (fp32 32-column kernel; the few
                 // tiles at the stream's ends run the full loop: counted as half all the same)
                 const bool half_last = !use16 && !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
@@ -2325,7 +2324,6 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 }
                 fa.tile_list = tl->d;
                 off = tl->blocks;
-                real_tiles = tl->real;
             }
             fa.groups = t->d_groups;
             fa.comb_tw = t->d_comb_tw;
