@@ -162,22 +162,80 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ Z, int N, int
     __syncthreads();
 }
 
-// Full forward FFT of N = 2^logN complex points in padded LDS (natural order in and out).
+// Output-pruned pass.  The kernel reads only the spectrum columns 0 .. M of a window group (vqt.rs:725-735 bounds them by the
+// decimated Nyquist), i.e. FFT bins 0 .. M and N - M .. N - 1 (the real split pairs c with N - c).  An output o of the pass with
+// stride p lands in residue k + r p of o mod p R (k = i mod p), and a later pass only moves it within that residue class of ITS
+// p' = p R — so the bins the kernel needs descend from the outputs with k + r p <= M or k + r p >= p R - M.  Once M < p that leaves
+// r = 0 (for k <= M) and r = R - 1 (for k >= p - M) of an item, and nothing at all of the items in between: two of R outputs
+// computed and written (out[0] = sum u_r, out[R-1] = sum u_r e^{+2 pi i r / R}), the other items not even loaded.  At 48 kHz /
+// 252 bins that is the last two of the 16 384-sample window's four passes (an LDS pass moves all N points whatever its radix).
+template <int R, int BLOCK, int E>
+__device__ __forceinline__ void stockham_pass_ends(float2* __restrict__ Z, int N, int p, const float2* __restrict__ tw, int tw_stride, int tid, int M) {
+    constexpr int NB = E / R;
+    const int T = N / R;
+    float2 lo[NB], hi[NB];
+    bool nl[NB], nh[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * BLOCK;
+        const int k = i & (p - 1);
+        nl[b] = i < T && k <= M;
+        nh[b] = i < T && k >= p - M;
+        lo[b] = make_float2(0.0f, 0.0f);
+        hi[b] = lo[b];
+        if (nl[b] || nh[b]) {
+            float2 u[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = Z[lpad(i + r * T)];
+            const int base = k * tw_stride;   // (p > M >= 0: never the first pass, the twiddles apply)
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[base * r]);
+            float2 s0 = u[0], s1 = u[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                constexpr int step = 16 / R;
+                const int idx = r * step;   // e^{+2 pi i idx / 16}
+                const float c = idx < 8 ? kC16[idx] : -kC16[idx - 8], sn = idx < 8 ? kS16[idx] : -kS16[idx - 8];
+                s0 = cadd(s0, u[r]);
+                s1 = cadd(s1, cmul(u[r], make_float2(c, sn)));
+            }
+            lo[b] = s0;
+            hi[b] = s1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * BLOCK;
+        const int k = i & (p - 1);
+        const int j = (i - k) * R + k;
+        if (nl[b]) Z[lpad(j)] = lo[b];
+        if (nh[b]) Z[lpad(j + (R - 1) * p)] = hi[b];
+    }
+    __syncthreads();
+}
+
+// Forward FFT of N = 2^logN complex points in padded LDS (natural order in and out); only the bins 0 .. M and N - M .. N - 1 are
+// guaranteed on return (M >= N / 2: all of them).
 template <int BLOCK, int E>
-__device__ __forceinline__ void lds_fft(float2* Z, int N, const float2* tw, int n_tw, int tid) {
+__device__ __forceinline__ void lds_fft(float2* Z, int N, const float2* tw, int n_tw, int tid, int M) {
     int p = 1;
     int rem = N;
     while (rem >= 16) {
-        stockham_pass<16, BLOCK, E>(Z, N, p, tw, n_tw / (p * 16), tid);
+        if (M < p) stockham_pass_ends<16, BLOCK, E>(Z, N, p, tw, n_tw / (p * 16), tid, M);
+        else stockham_pass<16, BLOCK, E>(Z, N, p, tw, n_tw / (p * 16), tid);
         p *= 16;
         rem >>= 4;
     }
     if (rem == 8) {
-        stockham_pass<8, BLOCK, E>(Z, N, p, tw, n_tw / (p * 8), tid);
+        if (M < p) stockham_pass_ends<8, BLOCK, E>(Z, N, p, tw, n_tw / (p * 8), tid, M);
+        else stockham_pass<8, BLOCK, E>(Z, N, p, tw, n_tw / (p * 8), tid);
     } else if (rem == 4) {
-        stockham_pass<4, BLOCK, E>(Z, N, p, tw, n_tw / (p * 4), tid);
+        if (M < p) stockham_pass_ends<4, BLOCK, E>(Z, N, p, tw, n_tw / (p * 4), tid, M);
+        else stockham_pass<4, BLOCK, E>(Z, N, p, tw, n_tw / (p * 4), tid);
     } else if (rem == 2) {
-        stockham_pass<2, BLOCK, E>(Z, N, p, tw, n_tw / (p * 2), tid);
+        if (M < p) stockham_pass_ends<2, BLOCK, E>(Z, N, p, tw, n_tw / (p * 2), tid, M);
+        else stockham_pass<2, BLOCK, E>(Z, N, p, tw, n_tw / (p * 2), tid);
     }
 }
 
@@ -327,7 +385,7 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
                 }
             }
             __syncthreads();
-            if (!(a.dev_skip & 2)) lds_fft<T, E>(Z, N, a.tw, a.n_tw, tl);
+            if (!(a.dev_skip & 2)) lds_fft<T, E>(Z, N, a.tw, a.n_tw, tl, (a.dev_skip & 4) ? N : G.n_cols - 1);   // (PVQ_FFT_SKIP=4: unpruned, for A/B)
             // real split, in place, only for the columns the kernel reads (c <= n_cols - 1 <= N): columns c and d = N - c
             // are both made of FFT bins c and N - c
             for (int c = tl; c <= N / 2; c += T) {
