@@ -65,7 +65,7 @@ def test_bandwidths_match_a_float64_restatement(kw):
 
 def test_default_kernel_has_no_coverage_gap_and_a_sharper_one_warns_like_the_reference():
     v = P.Vqt(P.VqtParameters(), device=None)
-    assert v.warnings == []
+    assert v.warnings == []   # the reference's own record: "the now-alive gap check confirms full -3 dB coverage (no warnings)", VQT_REVIEW.md:371-372
     q = 4.0
     w = P.Vqt(P.VqtParameters(quality=q, gamma=4.8 * q), device=None)
     lo, hi = w.bandwidth_3db_in_hz
