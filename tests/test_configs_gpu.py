@@ -304,7 +304,7 @@ def test_config3_full_size_shard_on_one_gpu():
         return d_db, d_mask, d_cnt
 
     a = run(d_pcm, F, s.n_lead)
-    assert v.last_algo() == P.ALGO_BLOCKDFT and v.last_frames_per_launch() == 65536
+    assert v.last_algo() == P.ALGO_BLOCKDFT and v.last_frames_per_launch() == 131072   # one sub-batch per rank
     b = run(d_pcm, F, s.n_lead)
     assert all(torch.equal(x, y) for x, y in zip(a, b))                                  # same input, same output
     assert torch.isfinite(a[0]).all() and float(a[0].min()) >= 0.0 and float(a[0].max()) <= 60.0 and int(a[2].sum()) > F

@@ -314,10 +314,11 @@ def test_blockdft_other_hops(hop):
 
 
 @pytest.mark.parametrize("hop", [64, 256])
-def test_blockdft_more_than_one_sub_batch(hop):
-    """More frames than one 65 536-frame sub-batch (the workspace, the stream rebasing and — at hop 64 — the partial-sum
-    buffer of the two-level tree are reused per sub-batch): frames around the seam and at the end against the FFT path
-    and the oracle."""
+def test_blockdft_more_than_one_sub_batch(hop, monkeypatch):
+    """More frames than one sub-batch (the workspace, the stream rebasing and — at hop 64 — the partial-sum buffer of the
+    two-level tree are reused per sub-batch): frames around the seam and at the end against the FFT path and the oracle.
+    Sub-batches are 131 072 frames by default; the developer knob (read per call) sets them to 65 536 here to keep the test small."""
+    monkeypatch.setenv("PVQ_CHUNK_FRAMES", "65536")
     pp, op = get_geom("bench_48k_252")
     v = P.Vqt.new(pp, 0)
     ov = O.OracleVqt(op)
