@@ -2302,8 +2302,21 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                             for (int ntl = 0; ntl < col_tiles(G); ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
                     }
                     size_t L = 0;
+                    // what a tile costs its workgroup, roughly in us: K loop (half for a last tile of at most 16 columns) + tree levels
+                    auto tile_cost = [&](const int4& e) {
+                        const BlockGroup& G = t->groups[e.x];
+                        const bool half = !use16 && e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
+                        return (half ? 8 : 16) + G.levels_f;
+                    };
                     for (auto& v : q) {
                         std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });   // by stripe; (group, row tile, column tile) order kept
+                        // the queue's last stripe: long tiles first, so that what is still running when the queues run dry is short (the launch's tail
+                        // is one workgroup life: 40 us of a 340 us launch, most slots idle)
+                        if (!v.empty()) {
+                            const int last = v.back().w;
+                            auto first_of_last = std::find_if(v.begin(), v.end(), [&](const int4& e) { return e.w == last; });
+                            std::stable_sort(first_of_last, v.end(), [&](const int4& x, const int4& y) { return tile_cost(x) > tile_cost(y); });
+                        }
                         L = std::max(L, v.size());
                     }
                     std::vector<int4> list(8 * L, make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
