@@ -358,6 +358,10 @@ class Vqt:
         matrix cores, fp32 accumulate: same parity bars, ~10 % faster end to end)"""
         _check(self._L.pvq_vqt_set_gemm_precision(self._h, precision))
 
+    def set_workspace_limit(self, n_bytes: int) -> None:
+        """upper bound of the block-DFT path's spectrum workspace (device bytes per handle; default 1 GiB): longer batches run in sub-batches"""
+        _check(self._L.pvq_vqt_set_workspace_limit(self._h, int(n_bytes)))
+
     def set_twiddle_fp16(self, enable: bool) -> None:
         """twiddle tables rounded to fp16, fp32 accumulation (BASELINE config 4's variant); rebuilds the tables"""
         _check(self._L.pvq_vqt_set_twiddle_fp16(self._h, int(bool(enable))))

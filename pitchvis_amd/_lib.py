@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpvq.so")
+# PVQ_DEV_LIB=1 selects the developer build of the same sources (libpvq_dev.so, -DPVQ_DEV_KNOBS: it alone reads the PVQ_* environment
+# knobs that the tile-shape / fallback tests, the A/B scripts and the phase-stamp tools use).  The product library reads no environment.
+LIB_PATH = os.path.join(_HERE, "lib", "libpvq_dev.so" if os.environ.get("PVQ_DEV_LIB") == "1" else "libpvq.so")
 
 # every symbol include/pvq.h declares
 EXPORTS = [
@@ -16,7 +18,7 @@ EXPORTS = [
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
-    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
+    "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_set_workspace_limit", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
     "pvq_analysis_state_update_vqt_smoothing_duration", "pvq_analysis_state_preprocess",
     "pvq_analysis_state_bin_to_frequency", "pvq_analysis_state_n_buckets", "pvq_analysis_state_get_field",
@@ -135,6 +137,7 @@ def load():
     L.pvq_vqt_last_algo.argtypes = [vp]; L.pvq_vqt_last_algo.restype = C.c_int
     L.pvq_vqt_blockdft_columns.argtypes = [vp]; L.pvq_vqt_blockdft_columns.restype = C.c_uint32
     L.pvq_vqt_set_gemm_precision.argtypes = [vp, C.c_int]; L.pvq_vqt_set_gemm_precision.restype = C.c_int
+    L.pvq_vqt_set_workspace_limit.argtypes = [vp, C.c_uint64]; L.pvq_vqt_set_workspace_limit.restype = C.c_int
     L.pvq_analysis_default_params.argtypes = [C.POINTER(CAnalysisParams)]
     L.pvq_analyze_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(CAnalysisParams), vp, vp, vp, vp, C.c_uint32, vp]
     L.pvq_analyze_batch_device.restype = C.c_int

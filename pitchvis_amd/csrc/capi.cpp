@@ -142,7 +142,7 @@ pvq_status pvq_vqt_create(const pvq_vqt_params* params, int device_id, pvq_vqt**
     try {
         if (!params || !out) return null_handle();
         *out = nullptr;
-        if (const char* t = std::getenv("PVQ_TEST_THROW")) {   // test hook for the exception barrier (tests/test_capi_hardening.py)
+        if (const char* t = pvq::dev_knob_str("PVQ_TEST_THROW")) {   // developer build only: test hook for the exception barrier (tests/test_capi_hardening.py)
             if (!std::strcmp(t, "bad_alloc")) throw std::bad_alloc();
             if (!std::strcmp(t, "length_error")) throw std::length_error("vector::_M_default_append");
             if (!std::strcmp(t, "int")) throw 42;
@@ -329,6 +329,14 @@ pvq_status pvq_vqt_set_twiddle_fp16(pvq_vqt* v, int enable) {
     try {
         if (!v) return null_handle();
         return v->impl->set_twiddle_fp16(enable != 0);
+    } catch (...) { return translate_exception(); }
+}
+
+pvq_status pvq_vqt_set_workspace_limit(pvq_vqt* v, uint64_t bytes) {
+    try {
+        if (!v) return null_handle();
+        v->impl->set_workspace_limit((size_t)bytes);
+        return PVQ_OK;
     } catch (...) { return translate_exception(); }
 }
 

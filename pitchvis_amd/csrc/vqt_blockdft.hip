@@ -41,12 +41,15 @@ constexpr int GM_BN = 64;   // granularity of the column tiling: 64 floats = 32 
 constexpr int CB_T = 128;    // frames per combine workgroup
 constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
-static size_t chunk_frames() {  // frames per sub-batch (the X workspace is sized for one: 0.74 GB at 48 kHz / 252 bins).  131 072: one sub-batch per rank of
-    // BASELINE configs[2]; against two of 65 536 the step is 4 % shorter (one ramp and one tail per kernel instead of two); sub-batches small enough for the
-    // Infinity Cache were measured no faster (32 768: 9 % slower)
-    const char* e = getenv("PVQ_CHUNK_FRAMES");  // developer knob (read per call)
-    const long v = e ? atol(e) : 131072;
-    return (size_t)(v >= 64 ? v : 131072);
+// Frames per sub-batch: the X (+ Y) workspace is sized for one.  As many as the handle's workspace limit holds (default 1 GiB:
+// 131 072 frames at 48 kHz / 252 bins = 0.74 GB; wide geometries — 840 bins: 15 KB per frame — take fewer), a multiple of 64,
+// at most 131 072: one sub-batch per rank of BASELINE configs[2]; against two of 65 536 the step is 4 % shorter (one ramp and
+// one tail per kernel instead of two); sub-batches small enough for the Infinity Cache were measured no faster (32 768: 9 % slower).
+static size_t chunk_frames(size_t limit_bytes, size_t bytes_per_frame) {
+    const long knob = dev_knob("PVQ_CHUNK_FRAMES", 0);   // (developer build; read per call)
+    if (knob >= 64) return (size_t)knob;
+    size_t f = limit_bytes / std::max<size_t>(bytes_per_frame, 1) / 64 * 64;
+    return std::min<size_t>(std::max<size_t>(f, 64), 131072);
 }
 
 struct BlockGroup {
@@ -112,27 +115,10 @@ struct BlockDftTables {
     struct TileList {
         int4* d = nullptr; size_t cap = 0;
         int nf = -1, bm = 0, blocks = 0;
-        int cols = 32;   // tile width the list was built for
-        int real = 0;   // entries that are tiles (the rest pads the eight per-XCD queues to one length)
     } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
     int tile_list_next = 0;
-    unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0, clk_per = 4;   // K-loop clock samples of the last profiled launch
-    // one-kernel form (vqt_fused2.hpp): E in 16x16x4 B-operand order, per (column tile, wave) kernel-product segments and their
-    // coefficients, the unit list of the last launch size, the power rows
-    bool f2_ok = false;   // the one-kernel form applies (hop 256, windows of <= 64 blocks, every group colours with 8 waves)
-    bool t2_ok = false;   // the pipelined GEMM + tree applies (hop 256, windows of <= 64 blocks)
-    float4* d_E16 = nullptr;
-    float4* d_E16h = nullptr;      // E in the B-operand order of the 16-column-tile kernel
-    int4* d_f2_segs = nullptr;
-    float2* d_f2_B = nullptr;
-    std::vector<int4> h_f2_segs;
-    struct UnitList {
-        int4* d = nullptr; size_t cap = 0;
-        int nf = -1, blocks = 0;
-        double gemm_mfma = 0.0, dots_mfma = 0.0;   // matrix instructions of one launch
-    } f2_units[2];
-    int f2_units_next = 0;
-    float* d_pw = nullptr; size_t pw_cap = 0;
+    unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch: 4 slots per sampled tile
+    float4* d_E16 = nullptr;       // E in the B-operand order of the 16x16x4 GEMM: [column tile][k < hop / 2][n < 16]
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -157,12 +143,6 @@ void free_blockdft_tables(BlockDftTables* t) {
         if (tl.d) (void)hipFree(tl.d);
     if (t->d_clk) (void)hipFree(t->d_clk);
     if (t->d_E16) (void)hipFree(t->d_E16);
-    if (t->d_E16h) (void)hipFree(t->d_E16h);
-    if (t->d_f2_segs) (void)hipFree(t->d_f2_segs);
-    if (t->d_f2_B) (void)hipFree(t->d_f2_B);
-    for (auto& ul : t->f2_units)
-        if (ul.d) (void)hipFree(ul.d);
-    if (t->d_pw) (void)hipFree(t->d_pw);
     delete t;
 }
 
@@ -175,6 +155,17 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // 16-byte raw buffer load.  Bound to the LLVM intrinsic by name: this compiler lowers
 // __builtin_amdgcn_raw_buffer_load_b64 / _b128 to a single-dword load.
 __device__ f32x4 pvq_raw_buffer_load_f32x4(i32x4 srsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
+// LDS-DMA (global_load_lds_*): 64 lanes x 16 (4) bytes from per-lane global addresses to wave-uniform LDS base + 16 (4) * lane, no register
+// destination; counted in vmcnt like any load.
+typedef __attribute__((address_space(1))) const void pvq_gvoid;
+typedef __attribute__((address_space(3))) void pvq_lvoid;
+__device__ __forceinline__ void lds_dma16(const void* g_lane, void* lds_wave) {
+    __builtin_amdgcn_global_load_lds((pvq_gvoid*)g_lane, (pvq_lvoid*)lds_wave, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma4(const void* g_lane, void* lds_wave) {
+    __builtin_amdgcn_global_load_lds((pvq_gvoid*)g_lane, (pvq_lvoid*)lds_wave, 4, 0, 0);
+}
 
 struct GemmArgs {
     const float* pcm_base;    // rebased per launch so that byte offsets fit 32 bits
@@ -212,18 +203,17 @@ struct GemmTreeArgs {
     int K;                    // hop
     long long base;           // index, relative to pcm_base, of the end of frame 0 of this launch
     int n_groups;
-    int blk_off[9];           // first block of each group (blocks of group g: n_tiles_g * mt8_g)
-    const int4* tile_list;    // optional: (group, column tile in the group, first frame, -) per workgroup — frame-stripe order, see launch
+    const int4* tile_list;    // (group, column tile in the group, first frame, position) per tile — frame-stripe order in eight queues, see launch
     const BlockGroup* groups;
+    BlockGroup gv[8];         // the same descriptors by value (the fused path takes at most 8 window groups): read from the kernel argument segment, not through a second dependent memory round trip
     const float2* comb_tw;
     const __bf16* Et;         // [3][Ntot][K] hi/mid/lo planes of E^T (split-bf16 form only)
     const float4* E16;        // [column tile][k < K / 2][n < 16]: (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}): B operands of the 16x16x4 fp32 form
-    const float4* E16h;       // 16-column tiles (vqt_gemm_tree16.hpp): [16-column tile][k group g = 2 G + h][lane 64][2]: (cos, -sin) of rows 32 G + 8 kq + 4 h + t, t = 0..3, column lane & 15
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
     unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader clock, 100 MHz clock) before and after its K loop
 };
 #define PVQ_STAMP(i) \
-    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)stamp_slot * 8 + (i)] = wall_clock64();   // stamp_slot: the tile's (workgroup's) row of the dump
 
 constexpr int FT_BM = 128, FT_BN = 64;
 
@@ -236,30 +226,18 @@ struct FusedTile {
     int nfr;      // rows this group produces: n_frames complete frames, or n_frames + nb - 64 partial sums when nb > 64
 };
 template <int BM = FT_BM>
-__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {
+__device__ __forceinline__ FusedTile fused_tile_of(const GemmTreeArgs& a, const int4& e) {   // tile list entry: (group, column tile, first frame, slot)
     FusedTile t;
-    if (a.tile_list) {
-        const int4 e = a.tile_list[blockIdx.x];
-        t.G = a.groups[e.x];
-        t.S = BM - t.G.nb_f + 1;
-        t.nfr = a.n_frames + t.G.nb - t.G.nb_f;
-        t.ntl = e.y;
-        t.f0 = e.z;
-        t.nt = t.G.tile0 + t.ntl;
-        return t;
-    }
-    int g = 0;
-    while (g + 1 < a.n_groups && (int)blockIdx.x >= a.blk_off[g + 1]) ++g;
-    t.G = a.groups[g];
+    t.G = a.gv[e.x];
     t.S = BM - t.G.nb_f + 1;
     t.nfr = a.n_frames + t.G.nb - t.G.nb_f;
-    const int r = blockIdx.x - a.blk_off[g];
-    const int xcd = r & 7, bi = r >> 3;                 // XCD-aware: an XCD owns whole row panels
-    t.ntl = bi % t.G.n_tiles;
-    t.f0 = ((bi / t.G.n_tiles) * 8 + xcd) * t.S;
+    t.ntl = e.y;
+    t.f0 = e.z;
     t.nt = t.G.tile0 + t.ntl;
     return t;
 }
+template <int BM = FT_BM>
+__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) { return fused_tile_of<BM>(a, a.tile_list[blockIdx.x]); }
 
 // doubling tree over the [128][32 complex] P tile in LDS (rows padded to 33 so that the transposed store
 // below is bank-conflict free), then the store of the S complete frames, column-major
@@ -309,7 +287,7 @@ __device__ __forceinline__ void fused_tree_register_levels(float2 (*A)[CB_C + 1]
 }
 
 template <int BM = FT_BM>   // BM rows, 2 * BM threads
-__device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid) {
+__device__ __forceinline__ void fused_tree_levels(float* smem, const float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid, int stamp_slot) {
     float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);  // [BM][33]
     const int c = tid & (CB_C - 1);
     constexpr int THREADS = 2 * BM;
@@ -373,8 +351,12 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
         __syncthreads();
     }
     PVQ_STAMP(2);
-    // lanes walk the frames of one column: 512-byte runs in memory, conflict-free LDS reads
-    const int j = tid % BM;   // (BM = 160: not a power of two)
+}
+// the tile's S complete frames to X (or Y): lanes walk the frames of one column: 512-byte runs in memory, conflict-free LDS reads
+template <int BM = FT_BM>
+__device__ __forceinline__ void fused_store_x(float* smem, const FusedTile& t, const GemmTreeArgs& a, int tid) {
+    float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);  // [BM][33]
+    const int j = tid % BM;
     const int f = t.f0 + j;
     if (j < t.S && f < t.nfr) {
         // windows of more than 64 blocks: 64-block partial sums go to Y, blockdft_tree_finish adds the last levels
@@ -385,6 +367,11 @@ __device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)
             __builtin_nontemporal_store((f32x2){val.x, val.y}, reinterpret_cast<f32x2*>(&dst[cc * 64]));   // one 8-byte store
         }
     }
+}
+template <int BM = FT_BM>
+__device__ __forceinline__ void fused_tree_store(float* smem, const float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int tid, int stamp_slot) {
+    fused_tree_levels<BM>(smem, tw, t, a, tid, stamp_slot);
+    fused_store_x<BM>(smem, t, a, tid);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);   // stores issued and acknowledged
         __syncthreads();
@@ -488,79 +475,117 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <int BM, bool HALF>   // tiles that lie wholly inside the stream (all but a handful per launch); HALF: at most 16 columns (a group's last tile): the second 16-column half is not computed
 __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
-                                                  f32x4a (&accR)[2][2], f32x4a (&accI)[2][2]) {
+                                                  f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
     constexpr int THREADS = 2 * BM;
-    constexpr bool VEC = true;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
     const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
     const int K2 = a.K / 2;
+    const int nG = K2 / 32;   // (K2 is a multiple of 32: the fused path takes hops that are multiples of 64)
     // A load step fetches a DOUBLE k group (32 mirrored sample pairs): lane (row, kq) takes the 8 consecutive samples 32 G + 8 kq ...
     // of its row and the 8 mirrored ones, two 16-byte loads each, issued back to back — the four lanes of a row read one whole
     // 128-byte line at a time.  Fetched 16 pairs at a time (one 64-byte half line per step, the other half a step later) every line
     // crossed the L2 -> L1 path twice: by then the CU's other waves had pushed it out of the L1 again, and the K loop ran at the
     // L2's 64-66 GB/s per CU, not at the matrix pipe's rate.  MFMA t of half h of double group G takes sample
     // 32 G + 8 kq + 4 h + t of every lane; the B rows follow that order.
-    long long jf0[2], jb0[2];
+    // Addresses: one loop-invariant byte offset per lane, row tile and direction; the double group moves in the instruction's
+    // SCALAR offset (front runs + 128 G bytes; the mirrored runs are anchored at the LAST double group and take + 128 (nG - 1 - G)).
+    unsigned vf[2], vb[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
-        jf0[mt] = row_lo + 8 * kq;
-        jb0[mt] = row_lo + a.K - 8 - 8 * kq;
+        vf[mt] = (unsigned)((row_lo + 8 * kq) * 4ll);
+        vb[mt] = (unsigned)((row_lo + a.K - 8 - 8 * kq) * 4ll) - 128u * (unsigned)(nG - 1);
     }
     float fr[2][2][8], bk[2][2][8];
+    // The prefetch is UNCONDITIONAL (the group index is clamped: past the last group the last one is fetched again into the idle
+    // buffer).  Inside a uniform `if` the compiler must place the s_waitcnt for the path on which the loads were NOT issued: it waited
+    // for vmcnt(4), then vmcnt(0) right after issuing the eight loads of the next group, i.e. for the loads it had just issued — the
+    // K loop ran with no prefetch distance at all, hidden only while a CU's other workgroup had its own K loop to run.
     auto load_dgroup = [&](int buf, int G) {   // G: double k group of the whole depth
+        const int Gc = G < nG - 1 ? G : nG - 1;
+        const int sf = 128 * Gc, sb = 128 * (nG - 1 - Gc);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            if (VEC) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jf0[mt] * 4u + 128u * (unsigned)G + 16u * h), 0, 0);
-                    const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)((unsigned)jb0[mt] * 4u - 128u * (unsigned)G + 16u * h), 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)vf[mt], sf + 16 * h, 0);   // (the half's 16 bytes ride in the scalar offset too: one address register per run)
+                const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)vb[mt], sb + 16 * h, 0);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        fr[buf][mt][4 * h + t] = v[t];
-                        bk[buf][mt][4 * h + t] = w[t];
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    fr[buf][mt][4 * h + t] = v[t];
+                    bk[buf][mt][4 * h + t] = w[t];
                 }
             }
         }
     };
     float4* El = reinterpret_cast<float4*>(smem);   // [rows][16]
-    auto mfma_half = [&](int buf, int Gl, int h) {  // Gl: double group inside the staged slice
-        const float4* e = El + (32 * Gl + 8 * kq + 4 * h) * 16 + m16;
-        float4 b[4];
+    // one k row = 8 MFMAs; its B operand (one 16-byte LDS read per lane) is fetched one row ahead, so that no MFMA waits on the LDS
+    const float4* erow = El + (8 * kq) * 16 + m16;   // row 32 Gl + 8 kq + 4 h + t of the staged slice
+    auto b_at = [&](int Gl, int h, int t) { return erow[(32 * Gl + 4 * h + t) * 16]; };
+    auto mfma_row = [&](int buf, int h, int t, const float4& b) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = e[t * 16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float sm = fr[buf][mt][4 * h + t] + bk[buf][mt][7 - 4 * h - t];
-                const float df = fr[buf][mt][4 * h + t] - bk[buf][mt][7 - 4 * h - t];
-                accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].x, accR[mt][0], 0, 0, 0);
-                if (!HALF) accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b[t].y, accR[mt][1], 0, 0, 0);
-                accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].z, accI[mt][0], 0, 0, 0);
-                if (!HALF) accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b[t].w, accI[mt][1], 0, 0, 0);
-            }
+        for (int mt = 0; mt < 2; ++mt) {
+            const float sm = fr[buf][mt][4 * h + t] + bk[buf][mt][7 - 4 * h - t];
+            const float df = fr[buf][mt][4 * h + t] - bk[buf][mt][7 - 4 * h - t];
+            accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b.x, accR[mt][0], 0, 0, 0);
+            if (!HALF) accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, b.y, accR[mt][1], 0, 0, 0);
+            accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b.z, accI[mt][0], 0, 0, 0);
+            if (!HALF) accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, b.w, accI[mt][1], 0, 0, 0);
         }
     };
-    const int nG = K2 / 32;   // (K2 is a multiple of 32: the fused path takes hops that are multiples of 64)
+    // the 8 k rows of double group Gl from operand buffer `buf`; bc: the first row's B operand (already fetched), returns the next group's
+    auto mfma_dgroup = [&](int buf, int Gl, float4 bc) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int h = r >> 2, t = r & 3;
+            // (past the slice's last row this reads on into the workgroup's LDS region: in bounds, never used)
+            const float4 bn = r < 7 ? b_at(Gl, (r + 1) >> 2, (r + 1) & 3) : b_at(Gl + 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // the next row's read is in flight before this row's MFMAs
+            mfma_row(buf, h, t, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            bc = bn;
+        }
+        return bc;
+    };
+    // The slice of E goes straight to LDS (LDS-DMA, 1 KB per wave instruction, no registers), issued ahead of the first operand
+    // loads: ONE memory round trip before the first MFMA.  (As a load -> wait -> ds_write loop it was four dependent round
+    // trips, each also waiting for the operand loads issued before it, behind two more for the tile's twiddles and descriptor.)
+    auto stage_e = [&](int kc, int rows) {   // 1 KB pieces of the slice (rows x 256 bytes), dealt to the waves; a full slice unrolled: all pieces in flight together
+        constexpr int NWV = THREADS / 64, FULL = FR_KC / 4 / NWV;
+        const float4* src = e_tile + (size_t)kc * 16 + wave * 64 + lane;
+        float4* dst = El + wave * 64;
+        if (rows == FR_KC && FR_KC / 4 % NWV == 0) {
+#pragma unroll
+            for (int q = 0; q < FULL; ++q) lds_dma16(src + q * (NWV * 64), dst + q * (NWV * 64));
+        } else {
+            for (int j = wave; j < rows / 4; j += NWV) lds_dma16(e_tile + (size_t)kc * 16 + j * 64 + lane, El + j * 64);
+        }
+    };
+    stage_e(0, K2 < FR_KC ? K2 : FR_KC);
+    for (int l = wave; l < tw_levels; l += THREADS / 64)   // the tile's combine twiddles: one level (32 complex = 64 floats) per wave instruction
+        lds_dma4(tw_src + (size_t)l * tw_stride, tw_dst + l * (2 * CB_C));
     load_dgroup(0, 0);
+    // (one wait for everything the prologue fetched.  Waiting only for the DMA pieces — s_waitcnt vmcnt(8) + a raw s_barrier — lets a
+    // wave start on its own first operands, but hipcc does not credit a hand-written wait: with an LDS-DMA "possibly in flight" it
+    // waits vmcnt(0) at the first use of every later load, which takes the K loop's prefetch distance away again.)
+    __syncthreads();
+    PVQ_STAMP(7);
     for (int kc = 0; kc < K2; kc += FR_KC) {
         const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
-        if (kc > 0) __syncthreads();   // every wave is done with the previous slice
-        for (int i = tid; i < rows * 16; i += THREADS) El[i] = e_tile[(size_t)kc * 16 + i];
-        __syncthreads();
+        if (kc > 0) {   // (hops of 512 and more: the next slice of E replaces the one every wave is done with)
+            __syncthreads();
+            stage_e(kc, rows);
+            __syncthreads();
+        }
         const int ng = rows / 32, G0 = kc / 32;
+        float4 bc = b_at(0, 0, 0);
         for (int Gl = 0; Gl < ng; Gl += 2) {   // two double groups per pass: buffer indices stay compile-time
-            if (G0 + Gl + 1 < nG) load_dgroup(1, G0 + Gl + 1);
-            mfma_half(0, Gl, 0);
-            mfma_half(0, Gl, 1);
+            load_dgroup(1, G0 + Gl + 1);
+            bc = mfma_dgroup(0, Gl, bc);
             if (Gl + 1 >= ng) break;           // (a 32-row slice: hop 64)
-            if (G0 + Gl + 2 < nG) load_dgroup(0, G0 + Gl + 2);
-            mfma_half(1, Gl + 1, 0);
-            mfma_half(1, Gl + 1, 1);
+            load_dgroup(0, G0 + Gl + 2);
+            bc = mfma_dgroup(1, Gl + 1, bc);
         }
     }
 }
@@ -571,7 +596,7 @@ __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* 
 // per step inside the register budget.
 template <int BM>
 __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
-                                                       f32x4a (&accR)[2][2], f32x4a (&accI)[2][2]) {
+                                                       f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
     constexpr int THREADS = 2 * BM;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
@@ -615,6 +640,7 @@ __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, fl
         }
     };
     load_group(0, 0);
+    for (int l = wave; l < tw_levels; l += THREADS / 64) tw_dst[l * (2 * CB_C) + lane] = tw_src[(size_t)l * tw_stride];
     for (int kc = 0; kc < K2; kc += FR_KC) {
         const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
         if (kc > 0) __syncthreads();   // every wave is done with the previous slice
@@ -640,8 +666,12 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     const FusedTile T = fused_tile<BM>(a);
     const int f0 = T.f0, nt = T.nt;
     if (f0 >= T.nfr) return;
+    const int stamp_slot = blockIdx.x;
     PVQ_STAMP(0);
-    if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
+    // the tile's combine twiddles (levels x 32 complex columns = 64 floats per level): wave l < levels copies level l, a dword per lane
+    const float* tw_src = reinterpret_cast<const float*>(a.comb_tw + T.G.tw_off + T.ntl * CB_C) + lane;   // level l: + l * tw_stride floats
+    float* tw_dst = reinterpret_cast<float*>(&tw_lds[0][0]);
+    const int tw_levels = T.G.levels_f, tw_stride = 2 * T.G.n_tiles * CB_C;
     const long long s = a.base + T.G.s_rel;
     const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
     const float4* e_tile = a.E16 + (size_t)nt * (a.K / 2) * 16;
@@ -664,11 +694,11 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     // a group's last column tile may hold 16 columns or fewer (3 of the 21 tiles at 48 kHz / 252 bins): half the MFMAs
     const bool half = T.ntl == T.G.n_tiles - 1 && T.G.n_cols - T.ntl * CB_C <= 16;
     if (!(tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes))
-        fused_f32_kloop16_edge<BM>(a, smem, tile_lo, e_tile, tid, accR, accI);
+        fused_f32_kloop16_edge<BM>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     else if (half)
-        fused_f32_kloop16<BM, true>(a, smem, tile_lo, e_tile, tid, accR, accI);
+        fused_f32_kloop16<BM, true>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     else
-        fused_f32_kloop16<BM, false>(a, smem, tile_lo, e_tile, tid, accR, accI);
+        fused_f32_kloop16<BM, false>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -691,7 +721,7 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     }
     __syncthreads();
     PVQ_STAMP(5);
-    fused_tree_store<BM>(smem, tw_lds, T, a, tid);
+    fused_tree_store<BM>(smem, tw_lds, T, a, tid, stamp_slot);
 }
 
 // Unfused form of the same GEMM (windows of more than 64 hop blocks: the tree runs as its own kernel over P' in memory):
@@ -889,7 +919,7 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
     }
     if (tid < 15 * FT_LDP) reinterpret_cast<float2*>(smem)[BM * FT_LDP + tid] = make_float2(0.0f, 0.0f);   // the spare rows
     __syncthreads();
-    fused_tree_store<BM>(smem, tw_lds, T, a, tid);
+    fused_tree_store<BM>(smem, tw_lds, T, a, tid, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1195,6 +1225,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
 
 template <int MT, int NW>   // 32-frame MFMA row tiles per workgroup, waves per workgroup
 __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs a) {
+    const int stamp_slot = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
@@ -1303,6 +1334,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int NW, int NS, int LDB>   // LDB: row stride of the LDS tile (4 mod 16, >= bins)
 __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArgs a) {
+    const int stamp_slot = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][LDB]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * 64;
@@ -1419,6 +1451,7 @@ constexpr int B3_NS = 3;   // 8-column stages in flight
 
 template <int MT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(BandArgs a) {
+    const int stamp_slot = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [MT * 32][ldb]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * (MT * 32);
@@ -1516,11 +1549,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
     }
 }
 
-}  // namespace pvq
-#include "vqt_fused2.hpp"
-#include "vqt_gemm_tree2.hpp"
-#include "vqt_gemm_tree16.hpp"
-namespace pvq {
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1543,19 +1571,13 @@ static inline float host_from_bf16(uint16_t h) {
 float Vqt::last_sclk_mhz() {
     if (!dev_ || !dev_->block || !dev_->block->d_clk || dev_->block->clk_n <= 0) return 0.0f;
     BlockDftTables* t = dev_->block;
-    const int per = t->clk_per;   // 4 slots per sample (two-kernel form) or 16 (one-kernel form: + per-pass stamps)
+    const int per = 4;
     std::vector<unsigned long long> h((size_t)t->clk_n * per);
     if (hipSetDevice(device_id_) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0.0f;
     if (hipMemcpy(h.data(), t->d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0.0f;
     std::vector<double> r;
     for (int i = 0; i < t->clk_n; ++i)
         if (h[per * i + 3] > h[per * i + 1]) r.push_back(100.0 * (double)(h[per * i + 2] - h[per * i]) / (double)(h[per * i + 3] - h[per * i + 1]));
-    if (const char* dump = getenv("PVQ_F2_STAMPS")) {   // developer knob: raw stamps of the sampled workgroups
-        if (FILE* fp = fopen(dump, "wb")) {
-            fwrite(h.data(), 8, h.size(), fp);
-            fclose(fp);
-        }
-    }
     if (r.empty()) return 0.0f;
     std::sort(r.begin(), r.end());
     return (float)r[r.size() / 2];
@@ -1874,12 +1896,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     std::vector<long long> tile_s(tile, 0);
     for (size_t g = 0; g < groups.size(); ++g)
         for (int tt = 0; tt < t->groups[g].n_tiles; ++tt) tile_s[t->groups[g].tile0 + tt] = t->groups[g].s_rel;
-    // ---- one-kernel form (vqt_fused2.hpp): hop 256, windows of at most 64 blocks
     std::vector<float4> E16;
-    std::vector<int4> f2_segs((size_t)tile * 8, make_int4(0, 0, 0, 0));
-    std::vector<float2> f2_B;
-    t->t2_ok = hop == 256 && t->nb_max <= 64;
-    t->f2_ok = t->t2_ok;
     {   // E in the B-operand order of the 16x16x4 GEMM: [column tile][k < hop / 2][n < 16]: (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16})
         const size_t K2 = hop / 2;
         E16.resize((size_t)tile * K2 * 16);
@@ -1890,121 +1907,12 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                     E16[((size_t)tt * K2 + m) * 16 + n] = make_float4(e[2 * n], e[2 * (n + 16)], e[2 * n + 1], e[2 * (n + 16) + 1]);
                 }
     }
-    std::vector<float4> E16h;
-    if (hop % 64 == 0) {   // E in the B-operand order of the 16-column-tile kernel: [16-column tile][k group][lane][2]
-        const size_t K2 = hop / 2, ng = K2 / 16;
-        const int t16n = tile * 2;
-        E16h.resize((size_t)t16n * ng * 128);
-        for (int t16 = 0; t16 < t16n; ++t16)
-            for (size_t g = 0; g < ng; ++g)
-                for (int l = 0; l < 64; ++l) {
-                    const int n = l & 15, kq = l >> 4;
-                    const int col = t16 * 16 + n;                                   // column of the padded 32-column-tile space
-                    float v[8];
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const size_t m = 32 * (g >> 1) + 8 * kq + 4 * (g & 1) + tt;   // the k order of fused_f32_kloop16
-                        const float* e = E.data() + m * ntot + (size_t)(col / CB_C) * GM_BN + 2 * (col % CB_C);
-                        v[2 * tt] = e[0];
-                        v[2 * tt + 1] = e[1];
-                    }
-                    E16h[(((size_t)t16 * ng + g) * 64 + l) * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
-                    E16h[(((size_t)t16 * ng + g) * 64 + l) * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
-                }
-    }
-    if (t->t2_ok) {
-        // Kernel-product blocks of 8 bins -> waves: a block is open from the column tile of its first column to that of its
-        // last; a wave holds one block's sums at a time, so blocks whose tile spans overlap need different waves (interval
-        // colouring: possible with 8 waves iff no tile has more than 8 open blocks).  Among the free waves the one with the
-        // least matrix work so far takes the block; waves w and w + 4 share a SIMD, so ties go 0, 1, 2, 3, 4, ...
-        for (size_t g = 0; g < groups.size() && t->f2_ok; ++g) {
-            const CsrMatrix& A = groups[g].filter_bank;
-            const CsrMatrix& Bm = groups[g].negative_filter_bank;
-            const BlockGroup& BG = t->groups[g];
-            int busy_until[8];
-            long long work[8];
-            for (int w = 0; w < 8; ++w) {
-                busy_until[w] = -1;
-                work[w] = 0;
-            }
-            for (uint32_t r0 = 0; r0 < A.rows; r0 += 8) {
-                const uint32_t r1 = std::min<uint32_t>(A.rows, r0 + 8);
-                int lo = 1 << 30, hi = -1;
-                for (uint32_t r = r0; r < r1; ++r) {
-                    for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
-                        lo = std::min(lo, idx_of[g][A.col_idx[q]]);
-                        hi = std::max(hi, idx_of[g][A.col_idx[q]]);
-                    }
-                    if (Bm.nnz() > 0)
-                        for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
-                            lo = std::min(lo, idx_of[g][Bm.col_idx[q]]);
-                            hi = std::max(hi, idx_of[g][Bm.col_idx[q]]);
-                        }
-                }
-                if (hi < 0) lo = hi = 0;   // rows without coefficients: one all-zero quad, so that their (zero) power is written
-                const int t_first = lo / CB_C, t_last = hi / CB_C;
-                int wsel = -1;
-                for (int w = 0; w < 8; ++w)
-                    if (busy_until[w] < t_first && (wsel < 0 || work[w] < work[wsel])) wsel = w;
-                if (wsel < 0) {
-                    t->f2_ok = false;
-                    break;
-                }
-                busy_until[wsel] = t_last;
-                for (int tt = t_first; tt <= t_last; ++tt) {
-                    const int c_lo = std::max(lo, tt * CB_C) - tt * CB_C, c_hi = std::min(hi, tt * CB_C + CB_C - 1) - tt * CB_C;
-                    const int q0 = c_lo / 4, q1 = c_hi / 4;
-                    const int nq = q1 - q0 + 1;
-                    const int boff = (int)(f2_B.size() / 64);
-                    f2_B.resize(f2_B.size() + (size_t)nq * 64, make_float2(0.0f, 0.0f));
-                    work[wsel] += nq;
-                    const int flags = (tt == t_first ? 1 : 0) | (tt == t_last ? 2 : 0);
-                    f2_segs[(size_t)(BG.tile0 + tt) * 8 + wsel] =
-                        make_int4(boff, q0 | (nq << 8) | (flags << 16) | ((int)(r1 - r0) << 24), (int)(groups[g].first_bin + r0), 0);
-                    // lane (n = l & 15: part = n >> 3, row = n & 7; kq = l >> 4) of quad q: column 4 (q0 + q) + kq of the tile
-                    auto at = [&](int ci, int part, int row) -> float2& {   // ci: the group's compressed column
-                        const int cl = ci - tt * CB_C;
-                        return f2_B[((size_t)boff + (cl / 4 - q0)) * 64 + (cl & 3) * 16 + part * 8 + row];
-                    };
-                    for (uint32_t r = r0; r < r1; ++r) {
-                        const int row = (int)(r - r0);
-                        for (uint32_t q = A.row_ptr[r]; q < A.row_ptr[r + 1]; ++q) {
-                            const int ci = idx_of[g][A.col_idx[q]];
-                            if (ci / CB_C != tt) continue;
-                            const double ar_ = A.values[q].re, ai_ = A.values[q].im;
-                            const float vr = (float)(ar_ * rho[g][ci].first - ai_ * rho[g][ci].second);
-                            const float vi = (float)(ar_ * rho[g][ci].second + ai_ * rho[g][ci].first);
-                            // y += v X: re += vr Xr - vi Xi, im += vi Xr + vr Xi   (.x multiplies Re X, .y multiplies Im X)
-                            at(ci, 0, row).x += vr;
-                            at(ci, 0, row).y += -vi;
-                            at(ci, 1, row).x += vi;
-                            at(ci, 1, row).y += vr;
-                        }
-                        if (Bm.nnz() > 0)
-                            for (uint32_t q = Bm.row_ptr[r]; q < Bm.row_ptr[r + 1]; ++q) {
-                                const int ci = idx_of[g][Bm.col_idx[q]];
-                                if (ci / CB_C != tt) continue;
-                                const double br_ = Bm.values[q].re, bi_ = Bm.values[q].im;
-                                const float wr = (float)(br_ * rho[g][ci].first - bi_ * rho[g][ci].second);
-                                const float wi = (float)(br_ * rho[g][ci].second + bi_ * rho[g][ci].first);
-                                // y += conj(w X): re += wr Xr - wi Xi, im += -wi Xr - wr Xi
-                                at(ci, 0, row).x += wr;
-                                at(ci, 0, row).y += -wi;
-                                at(ci, 1, row).x += -wi;
-                                at(ci, 1, row).y += -wr;
-                            }
-                    }
-                }
-            }
-        }
-    }
-    if (f2_B.empty()) f2_B.resize(64, make_float2(0.0f, 0.0f));
-    t->h_f2_segs = f2_segs;
     t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
               up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
-              up(&t->d_E16, E16) && (E16h.empty() || up(&t->d_E16h, E16h)) && (!t->t2_ok || (up(&t->d_f2_segs, f2_segs) && up(&t->d_f2_B, f2_B)));
+              up(&t->d_E16, E16);
     if (!ok) {
         free_blockdft_tables(t);
         set_last_error("hipMalloc/hipMemcpy failed while building block-DFT tables");
@@ -2023,19 +1931,13 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     if (st != PVQ_OK) return st;
     BlockDftTables* t = dev_->block;
     const int ntot = t->n_tiles * GM_BN, xc = t->n_tiles * CB_C;
-    const size_t chunk = std::min(n_frames, chunk_frames());
-    const size_t rows_cap = chunk + t->nb_max - 1;
     // X is blocked by 64-frame tiles: [tile][column][64 frames], so the kernel-product workgroup of a tile streams one
     // contiguous region (and a column step is a constant 512 bytes); X_PAD_COLS zeroed columns close every tile
     const int xcp = xc + X_PAD_COLS;
+    const size_t chunk = std::min(n_frames, chunk_frames(workspace_limit_, (size_t)xcp * sizeof(float2) * (t->nb_max > 64 ? 2 : 1)));
+    const size_t rows_cap = chunk + t->nb_max - 1;
     const size_t x_bytes = (chunk + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
-    // the one-kernel form (vqt_fused2.hpp) keeps the spectrum on chip: no X workspace at all
-    static const int f2_env = getenv("PVQ_FUSED2") ? atoi(getenv("PVQ_FUSED2")) : 0;   // developer knob: 1 = the one-kernel form (experiment: parity-green, slower)
-    static const int t2_env = getenv("PVQ_GEMM_TREE2") ? atoi(getenv("PVQ_GEMM_TREE2")) : 0;   // developer knob: 1 = the pipelined blockdft_gemm_tree2 instead of blockdft_gemm_tree (experiment: parity-green, slower)
-    static const bool fuse_env0 = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));
-    const bool use_f2 = f2_env && fuse_env0 && t->f2_ok && !gemm_split_bf16_ && t->n_groups <= 8;
-    const bool use_t2 = !use_f2 && t2_env && fuse_env0 && t->t2_ok && !gemm_split_bf16_ && t->n_groups <= 8;
-    if (!use_f2 && t->x_cap < x_bytes) {
+    if (t->x_cap < x_bytes) {
         if (t->d_X) PVQ_HIP(hipFree(t->d_X));
         t->d_X = nullptr; t->x_cap = 0;
         PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_X), x_bytes));
@@ -2043,7 +1945,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         t->x_cap = x_bytes;
     }
     const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
-    static const bool fuse_env = !(getenv("PVQ_NO_FUSE") && atoi(getenv("PVQ_NO_FUSE")));  // developer knob
+    static const bool fuse_env = !dev_knob("PVQ_NO_FUSE", 0);
     const bool fused = fuse_env && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
     if (fused && t->nb_max > 64) {
         const size_t y_bytes = (chunk + (size_t)(t->nb_max - 64) + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
@@ -2083,19 +1985,6 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
     const int nb = (int)n_bins();
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     float2* X = t->d_X;
-    const size_t pw_stride = (chunk + 63) / 64 * 64;
-    if (use_f2) {
-        const size_t pw_bytes = (size_t)n_bins() * pw_stride * sizeof(float);
-        if (t->pw_cap < pw_bytes) {
-            if (t->d_pw) PVQ_HIP(hipFree(t->d_pw));
-            t->d_pw = nullptr; t->pw_cap = 0;
-            PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_pw), pw_bytes));
-            t->pw_cap = pw_bytes;
-        }
-        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_fused2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS_BYTES));
-        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_fused2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS_BYTES));
-    }
-    if (use_t2) PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blockdft_gemm_tree2), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
     for (size_t c = 0; c < n_chunks; ++c) {
         const size_t fbeg = c * chunk;
         const size_t nf = std::min(chunk, n_frames - fbeg);
@@ -2108,140 +1997,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         const float* pcm_base = d_pcm + rebase;
         const unsigned pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
         const long long base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
-        BlockDftTables::UnitList* ul = nullptr;
-        if (use_f2 || use_t2) {
-            // unit list: (window group, 256-block row tile), frame-stripe order as for the two-kernel form (a stripe of 2 048
-            // frames belongs to one XCD: workgroup b runs on XCD b & 7), kept per launch size
-            for (auto& u : t->f2_units)
-                if (u.nf == (int)nf) ul = &u;
-            if (!ul) {
-                ul = &t->f2_units[t->f2_units_next];
-                t->f2_units_next ^= 1;
-                const int FS = 2048;
-                std::vector<std::vector<int4>> q(8);
-                double gm = 0.0, dm = 0.0;
-                for (int g = 0; g < t->n_groups; ++g) {
-                    const BlockGroup& G = t->groups[g];
-                    const int S = 257 - G.nb_f;
-                    double dq = 0.0;
-                    for (int tt = 0; tt < G.n_tiles; ++tt)
-                        for (int w = 0; w < 8; ++w) dq += (t->h_f2_segs[(size_t)(G.tile0 + tt) * 8 + w].y >> 8) & 0xff;
-                    for (int f0 = 0; f0 < (int)nf; f0 += S) {
-                        q[(f0 / FS) & 7].push_back(make_int4(g, f0, 0, f0 / FS));
-                        gm += (double)G.n_tiles * 8 * 256;   // 8 waves x 256 MFMAs per column tile
-                        dm += dq * 32;                       // 16 frame tiles x (Re, Im) per column quad
-                    }
-                }
-                size_t L = 0;
-                for (auto& v : q) {
-                    std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });
-                    L = std::max(L, v.size());
-                }
-                std::vector<int4> list(8 * L, make_int4(0, 0x3FFFFFFF, 0, 0));   // padding entries: past every group's frames
-                for (int x = 0; x < 8; ++x)
-                    for (size_t i = 0; i < q[x].size(); ++i) list[i * 8 + x] = q[x][i];
-                if (ul->cap < list.size()) {
-                    if (ul->d) PVQ_HIP(hipFree(ul->d));
-                    ul->d = nullptr; ul->cap = 0;
-                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&ul->d), list.size() * sizeof(int4)));
-                    ul->cap = list.size();
-                }
-                PVQ_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read this slot
-                PVQ_HIP(hipMemcpy(ul->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
-                ul->nf = (int)nf;
-                ul->blocks = (int)list.size();
-                ul->gemm_mfma = gm;
-                ul->dots_mfma = dm;
-            }
-        }
-        if (use_f2) {
-            F2Args fa;
-            fa.pcm_base = pcm_base;
-            fa.pcm_bytes = pcm_bytes;
-            fa.E16 = t->d_E16;
-            fa.K = (int)hop;
-            fa.n_frames = (int)nf;
-            fa.base = base;
-            fa.units = ul->d;
-            fa.groups = t->d_groups;
-            fa.comb_tw = t->d_comb_tw;
-            fa.segs = t->d_f2_segs;
-            fa.B2 = t->d_f2_B;
-            fa.pw = t->d_pw;
-            fa.pw_stride = (int)pw_stride;
-            fa.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
-            fa.n_bins = nb;
-            fa.clk = nullptr;
-            static const int f2_exp = getenv("PVQ_F2_EXP") ? atoi(getenv("PVQ_F2_EXP")) : 0;
-            fa.exp = f2_exp;
-            // flop the kernel's matrix instructions issue (v_mfma_f32_16x16x4_f32: 2 048 each): GEMM tiles + kernel-product quads
-            last_gemm_flop_ = (ul->gemm_mfma + ul->dots_mfma) * 2048.0;
-            if (profiling_) {
-                const size_t need = ((size_t)ul->blocks / 16 + 1) * 16 * sizeof(unsigned long long);
-                if (t->clk_cap < need) {
-                    if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
-                    t->d_clk = nullptr; t->clk_cap = 0;
-                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_clk), need));
-                    t->clk_cap = need;
-                }
-                PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
-                t->clk_n = ul->blocks / 16 + 1;
-                t->clk_per = 16;
-                fa.clk = t->d_clk;
-            }
-            slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-            if (fa.out_cplx)
-                hipLaunchKernelGGL(blockdft_fused2<true>, dim3(ul->blocks), dim3(512), F2_LDS_BYTES, stream, fa);
-            else
-                hipLaunchKernelGGL(blockdft_fused2<false>, dim3(ul->blocks), dim3(512), F2_LDS_BYTES, stream, fa);
-            slot_end(SLOT_BLOCKDFT_GEMM, stream);
-            PowArgs pa;
-            pa.pw = t->d_pw;
-            pa.pw_stride = (int)pw_stride;
-            pa.b = BandArgs{};
-            pa.b.n_frames = (int)nf;
-            pa.b.n_bins = nb;
-            pa.b.ldb = nb | 1;
-            pa.b.out_db = d_out_db + fbeg * nb;
-            pa.b.status = dev_->d_status;
-            slot_begin(SLOT_BLOCKDFT_DOTS, stream);
-            hipLaunchKernelGGL(power_rows_to_db, dim3((unsigned)((nf + 31) / 32)), dim3(256), sizeof(float) * 32 * pa.b.ldb, stream, pa);
-            slot_end(SLOT_BLOCKDFT_DOTS, stream);
-            continue;
-        }
-        if (use_t2) {
-            T2Args ta;
-            ta.pcm_base = pcm_base;
-            ta.pcm_bytes = pcm_bytes;
-            ta.E16 = t->d_E16;
-            ta.K = (int)hop;
-            ta.n_frames = (int)nf;
-            ta.base = base;
-            ta.units = ul->d;
-            ta.groups = t->d_groups;
-            ta.comb_tw = t->d_comb_tw;
-            ta.X = X;
-            ta.x_bytes = (unsigned)std::min<size_t>(x_bytes, 0x7FFFFFF0u);
-            ta.xcp = xcp;
-            ta.clk = nullptr;
-            last_gemm_flop_ = ul->gemm_mfma * 2048.0;   // v_mfma_f32_16x16x4_f32: 2 048 flop each
-            if (profiling_) {
-                const size_t need = ((size_t)ul->blocks / 16 + 1) * 16 * sizeof(unsigned long long);
-                if (t->clk_cap < need) {
-                    if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
-                    t->d_clk = nullptr; t->clk_cap = 0;
-                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_clk), need));
-                    t->clk_cap = need;
-                }
-                PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
-                t->clk_n = ul->blocks / 16 + 1;
-                t->clk_per = 16;
-                ta.clk = t->d_clk;
-            }
-            slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-            hipLaunchKernelGGL(blockdft_gemm_tree2, dim3(ul->blocks), dim3(512), T2_LDS_BYTES, stream, ta);
-            slot_end(SLOT_BLOCKDFT_GEMM, stream);
-        } else if (fused) {
+        if (fused) {
             GemmTreeArgs fa;
             fa.pcm_base = pcm_base;
             fa.pcm_bytes = pcm_bytes;
@@ -2254,98 +2010,82 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.K = (int)hop;
             fa.base = base;
             fa.n_groups = t->n_groups;
-            static const int dyn_lds_env = getenv("PVQ_DYN_LDS") ? atoi(getenv("PVQ_DYN_LDS")) : 0;   // developer knob: extra LDS -> 1 workgroup per CU
-            static const int bm_env = getenv("PVQ_FUSED_BM") ? atoi(getenv("PVQ_FUSED_BM")) : 0;   // developer knob
-            // 256-row tiles for the split-bf16 form: 257 - Nb complete frames per tile (1.08x row recomputation instead
-            // of 1.2x) and the E^T planes staged once per 256 rows; measured 7 % faster than 128-row tiles
-            const int fused_bm = (bm_env == 160 && !use_bf) ? 160 : (bm_env != 128 ? 256 : FT_BM);   // 160: three workgroups per CU (fp32 form)
-            // 16-column tiles (vqt_gemm_tree16.hpp): three workgroups per CU instead of two; fp32 form, 256-row tiles, frame-stripe order
-            static const int tile16_env = getenv("PVQ_TILE16") ? atoi(getenv("PVQ_TILE16")) : 0;   // developer knob while the form is being measured
-            const bool use16 = tile16_env && !use_bf && fused_bm == 256 && hop % 64 == 0 && t->d_E16h != nullptr;
-            const int tile_cols = use16 ? 16 : CB_C;
-            auto col_tiles = [&](const BlockGroup& G) { return use16 ? (G.n_cols + 15) / 16 : G.n_tiles; };
-            int off = 0;
+            static const int dyn_lds_env = dev_knob("PVQ_DYN_LDS", 0);      // extra LDS -> one workgroup per CU
+            static const int bm_env = dev_knob("PVQ_FUSED_BM", 0);          // 128: 128-row tiles (the tile-shape bit-identity test)
+            // 256-row tiles: 257 - Nb complete frames per tile (1.08x row recomputation instead of 1.2x with 128 rows)
+            const int fused_bm = bm_env == 128 && !use_bf ? 128 : 256;
             double eff_tiles = 0.0;   // matrix work of the launch in whole-tile units
             for (int g = 0; g < t->n_groups; ++g) {
-                fa.blk_off[g] = off;
                 const int S = fused_bm - t->groups[g].nb_f + 1;
                 const int rows_g = (int)nf + t->groups[g].nb - t->groups[g].nb_f;
-                const int mt8 = (((rows_g + S - 1) / S) + 7) / 8 * 8;
-                off += col_tiles(t->groups[g]) * mt8;
-                // matrix work in whole-tile units: a last tile of at most 16 columns runs half the MFMAs (fp32 32-column kernel; the few
-                // tiles at the stream's ends run the full loop: counted as half all the same)
-                const bool half_last = !use16 && !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
-                eff_tiles += (col_tiles(t->groups[g]) - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
+                // a last tile of at most 16 columns runs half the MFMAs (fp32 kernel; the few tiles at the stream's ends run the full
+                // loop: counted as half all the same)
+                const bool half_last = !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
+                eff_tiles += (t->groups[g].n_tiles - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
             }
-            for (int g = t->n_groups; g < 9; ++g) fa.blk_off[g] = off;
-            // Frame-stripe order (developer knob PVQ_TILE_ORDER=0 keeps the group-major order above): the stream is cut into
-            // stripes of 2 048 frames, stripe s belongs to XCD s & 7 (workgroup b runs on XCD b & 7), and an XCD takes its
-            // stripes in order, within a stripe every group's row tiles with all their column tiles.  All five window groups
-            // then read a stripe's PCM rows from that XCD's L2 while they are resident (once per stripe, not once per group).
-            static const int tile_order_env = getenv("PVQ_TILE_ORDER") ? atoi(getenv("PVQ_TILE_ORDER")) : 1;
-            fa.tile_list = nullptr;
-            if (tile_order_env || use16) {
-                BlockDftTables::TileList* tl = nullptr;
-                for (auto& c : t->tile_lists)
-                    if (c.nf == (int)nf && c.bm == fused_bm && c.cols == tile_cols) tl = &c;
-                if (!tl) {
-                    tl = &t->tile_lists[t->tile_list_next];
-                    t->tile_list_next ^= 1;
-                    static const int fs_env = getenv("PVQ_TILE_FS") ? atoi(getenv("PVQ_TILE_FS")) : 2048;   // developer knob
-                    const int FS = fs_env;
-                    std::vector<std::vector<int4>> q(8);
-                    for (int g = 0; g < t->n_groups; ++g) {
-                        const BlockGroup& G = t->groups[g];
-                        const int S = fused_bm - G.nb_f + 1;
-                        const int rows_g = (int)nf + G.nb - G.nb_f;
-                        for (int f0 = 0; f0 < rows_g; f0 += S)
-                            for (int ntl = 0; ntl < col_tiles(G); ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
-                    }
-                    size_t L = 0;
-                    // what a tile costs its workgroup, roughly in us: K loop (half for a last tile of at most 16 columns) + tree levels
-                    auto tile_cost = [&](const int4& e) {
-                        const BlockGroup& G = t->groups[e.x];
-                        const bool half = !use16 && e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
-                        return (half ? 8 : 16) + G.levels_f;
-                    };
-                    for (auto& v : q) {
-                        std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });   // by stripe; (group, row tile, column tile) order kept
-                        // the queue's last stripe: long tiles first, so that what is still running when the queues run dry is short (the launch's tail
-                        // is one workgroup life: 40 us of a 340 us launch, most slots idle)
-                        if (!v.empty()) {
-                            const int last = v.back().w;
-                            auto first_of_last = std::find_if(v.begin(), v.end(), [&](const int4& e) { return e.w == last; });
-                            std::stable_sort(first_of_last, v.end(), [&](const int4& x, const int4& y) { return tile_cost(x) > tile_cost(y); });
-                        }
-                        L = std::max(L, v.size());
-                    }
-                    std::vector<int4> list(8 * L, make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
-                    for (int x = 0; x < 8; ++x)
-                        for (size_t i = 0; i < q[x].size(); ++i) list[i * 8 + x] = q[x][i];
-                    if (tl->cap < list.size()) {
-                        if (tl->d) PVQ_HIP(hipFree(tl->d));
-                        tl->d = nullptr; tl->cap = 0;
-                        PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&tl->d), list.size() * sizeof(int4)));
-                        tl->cap = list.size();
-                    }
-                    PVQ_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read this slot
-                    PVQ_HIP(hipMemcpy(tl->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
-                    tl->nf = (int)nf;
-                    tl->bm = fused_bm;
-                    tl->cols = tile_cols;
-                    tl->blocks = (int)list.size();
-                    tl->real = 0;
-                    for (auto& v : q) tl->real += (int)v.size();
+            // Frame-stripe tile order: the stream is cut into stripes of 2 048 frames, stripe s belongs to XCD queue s & 7 (workgroup b
+            // runs on the XCD of all b' = b mod 8), and a queue takes its stripes in order, within a stripe every group's row tiles with
+            // all their column tiles.  All window groups then read a stripe's PCM rows from that XCD's L2 while they are resident (once
+            // per stripe, not once per group).  Entry: (group, column tile, first frame, position i * 8 + queue).
+            BlockDftTables::TileList* tl = nullptr;
+            for (auto& c : t->tile_lists)
+                if (c.nf == (int)nf && c.bm == fused_bm) tl = &c;
+            if (!tl) {
+                tl = &t->tile_lists[t->tile_list_next];
+                t->tile_list_next ^= 1;
+                static const int FS = dev_knob("PVQ_TILE_FS", 2048);
+                std::vector<std::vector<int4>> q(8);
+                for (int g = 0; g < t->n_groups; ++g) {
+                    const BlockGroup& G = t->groups[g];
+                    const int S = fused_bm - G.nb_f + 1;
+                    const int rows_g = (int)nf + G.nb - G.nb_f;
+                    for (int f0 = 0; f0 < rows_g; f0 += S)
+                        for (int ntl = 0; ntl < G.n_tiles; ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
                 }
-                fa.tile_list = tl->d;
-                off = tl->blocks;
+                size_t L = 0;
+                // what a tile costs its workgroup, roughly in us: K loop (half for a last tile of at most 16 columns) + tree levels
+                auto tile_cost = [&](const int4& e) {
+                    const BlockGroup& G = t->groups[e.x];
+                    const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
+                    return (half ? 8 : 16) + G.levels_f;
+                };
+                for (auto& v : q) {
+                    std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });   // by stripe; (group, row tile, column tile) order kept
+                    // the queue's last stripe: long tiles first, so that what is still running when the queues run dry is short
+                    if (!v.empty()) {
+                        const int last = v.back().w;
+                        auto first_of_last = std::find_if(v.begin(), v.end(), [&](const int4& e) { return e.w == last; });
+                        std::stable_sort(first_of_last, v.end(), [&](const int4& x, const int4& y) { return tile_cost(x) > tile_cost(y); });
+                    }
+                    L = std::max(L, v.size());
+                }
+                std::vector<int4> list(8 * std::max<size_t>(L, 1), make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
+                for (int x = 0; x < 8; ++x) {
+                    for (size_t i = 0; i < q[x].size(); ++i) {
+                        list[i * 8 + x] = q[x][i];
+                        list[i * 8 + x].w = (int)(i * 8 + x);
+                    }
+                }
+                if (tl->cap < list.size()) {
+                    if (tl->d) PVQ_HIP(hipFree(tl->d));
+                    tl->d = nullptr; tl->cap = 0;
+                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&tl->d), list.size() * sizeof(int4)));
+                    tl->cap = list.size();
+                }
+                PVQ_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read this slot
+                PVQ_HIP(hipMemcpy(tl->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
+                tl->nf = (int)nf;
+                tl->bm = fused_bm;
+                tl->blocks = (int)list.size();
             }
+            fa.tile_list = tl->d;
+            const int off = tl->blocks;   // list entries = workgroups of the non-persistent forms = rows of the stamp dump
             fa.groups = t->d_groups;
+            for (int g = 0; g < 8; ++g) fa.gv[g] = t->groups[std::min(g, t->n_groups - 1)];
             fa.comb_tw = t->d_comb_tw;
             fa.Et = t->d_Et;
             fa.E16 = t->d_E16;
-            fa.E16h = t->d_E16h;
-            static const char* stamps_env = getenv("PVQ_STAMPS");   // developer knob: dump per-workgroup phase stamps once
+            static const char* stamps_env = dev_knob_str("PVQ_STAMPS");   // dump per-tile phase stamps of the first launch
             static bool stamps_done = false;
             const bool do_stamps = stamps_env && !stamps_done;
             fa.stamps = nullptr;
@@ -2353,7 +2093,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 8 * 8 + 8));
             // flop the GEMM's matrix instructions issue in this launch: tiles x rows x 64 real columns x depth x 2
             // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
-            last_gemm_flop_ = eff_tiles * fused_bm * (2 * tile_cols) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
+            last_gemm_flop_ = eff_tiles * fused_bm * (2 * CB_C) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
             fa.clk = nullptr;
             if (profiling_ && !use_bf) {
                 const size_t need = ((size_t)off / 64 + 1) * 4 * sizeof(unsigned long long);
@@ -2365,20 +2105,13 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 }
                 PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
                 t->clk_n = off / 64 + 1;
-                t->clk_per = 4;
                 fa.clk = t->d_clk;
             }
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-            if (use_bf && fused_bm == 256)
+            if (use_bf)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
-            else if (use_bf)
-                hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<128>, dim3(off), dim3(256), 0, stream, fa);
-            else if (use16)
-                hipLaunchKernelGGL(blockdft_gemm_tree16<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
-            else if (fused_bm == 160)
-                hipLaunchKernelGGL(blockdft_gemm_tree<160>, dim3(off), dim3(320), 0, stream, fa);
             else
                 hipLaunchKernelGGL(blockdft_gemm_tree<128>, dim3(off), dim3(256), 0, stream, fa);
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
@@ -2470,7 +2203,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.out_db = d_out_db + fbeg * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
         da.status = dev_->d_status;
-        static const char* dstamps_env = getenv("PVQ_STAMPS_DOTS");   // developer knob: dump per-workgroup phase stamps once
+        static const char* dstamps_env = dev_knob_str("PVQ_STAMPS_DOTS");   // dump per-workgroup phase stamps of the first launch
         static bool dstamps_done = false;
         const bool do_dstamps = dstamps_env && !dstamps_done;
         da.stamps = nullptr;
@@ -2479,8 +2212,8 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         if (do_dstamps) PVQ_HIP(hipMemset(da.stamps, 0, n_wg * 8 * 8));
         slot_begin(SLOT_BLOCKDFT_DOTS, stream);
         const int mt = wide ? 2 : 1;
-        static const int dots16_env = getenv("PVQ_DOTS_16BIN") ? atoi(getenv("PVQ_DOTS_16BIN")) : 0;   // developer knob: the 32x32x2 form
-        static const int dots_f32_env = getenv("PVQ_DOTS_F32") ? atoi(getenv("PVQ_DOTS_F32")) : 0;   // developer knob
+        static const int dots16_env = dev_knob("PVQ_DOTS_16BIN", 0);   // the 32x32x2 form
+        static const int dots_f32_env = dev_knob("PVQ_DOTS_F32", 0);
         const bool dots_split = gemm_split_bf16_ && !dots_f32_env;   // the kernel product follows the GEMM arithmetic
         const size_t lds = sizeof(float) * 32 * mt * da.ldb;
         const dim3 grid((unsigned)((nf + 32 * mt - 1) / (32 * mt)));
@@ -2495,7 +2228,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 da.B = t->d_band_B8;
                 da.list = t->d_band_list8;
                 da.per_wave = t->band_per_wave8;
-                static const int ns_env = getenv("PVQ_DOTS_NS") ? atoi(getenv("PVQ_DOTS_NS")) : 0;   // developer knob: operand ring depth
+                static const int ns_env = dev_knob("PVQ_DOTS_NS", 0);   // operand ring depth
                 if (wide308)
                     hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS, BAND_LDB3>), grid, dim3(512), lds, stream, da);
                 else if (ns_env == 3)

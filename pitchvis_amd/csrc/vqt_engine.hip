@@ -845,7 +845,7 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     a.out_db = d_out_db;
     a.out_cplx = reinterpret_cast<float2*>(d_out_cplx);
     a.status = dev_->d_status;
-    static const int skip_env = getenv("PVQ_FFT_SKIP") ? atoi(getenv("PVQ_FFT_SKIP")) : 0;
+    static const int skip_env = dev_knob("PVQ_FFT_SKIP", 0);   // (developer build only: timing probes that skip stages)
     a.dev_skip = skip_env;
 
     // threads per frame: one radix-16 butterfly per thread and pass for the largest window; 512-thread workgroups hold

@@ -17,6 +17,20 @@
 
 namespace pvq {
 
+// Developer knobs are environment variables that only the DEVELOPER build of the library reads (-DPVQ_DEV_KNOBS: libpvq_dev.so,
+// used by the tile-shape / fallback tests, the A/B scripts and the phase-stamp tools).  The product library never looks at the
+// environment: a stray variable in a consumer's process cannot change what it computes.  Table of knobs: DESIGN.md.
+#ifdef PVQ_DEV_KNOBS
+inline int dev_knob(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+inline const char* dev_knob_str(const char* name) { return std::getenv(name); }
+#else
+inline int dev_knob(const char*, int dflt) { return dflt; }
+inline const char* dev_knob_str(const char*) { return nullptr; }
+#endif
+
 // analysis.rs:72-98 (peak-related fields)
 struct AnalysisParameters {
     float peak_min_prominence = 10.0f;
@@ -64,6 +78,7 @@ class Vqt {
     void set_algo(pvq_algo a) { algo_ = a; }
     // block-DFT GEMM arithmetic: exact fp32 MFMA, or the split-bf16 (3 x bf16, fp32 accumulate) form
     void set_gemm_split_bf16(bool on) { gemm_split_bf16_ = on; }
+    void set_workspace_limit(size_t bytes) { workspace_limit_ = bytes ? bytes : ((size_t)1 << 30); }   // block-DFT spectrum workspace
     // rebuilds the device tables with every twiddle factor rounded to fp16 (or back to fp32)
     pvq_status set_twiddle_fp16(bool on);
     bool twiddle_fp16() const { return twiddle_fp16_; }
@@ -119,6 +134,7 @@ class Vqt {
     hipStream_t host_streams_[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> host_events_;
     bool twiddle_fp16_ = false;
+    size_t workspace_limit_ = (size_t)1 << 30;   // bytes of X (+ Y) a sub-batch of the block-DFT path may take
     bool gemm_split_bf16_ = false;  // default PVQ_GEMM_F32; PVQ_GEMM_BF16X3 meets the same parity bars and is ~10 % faster end to end
     uint32_t last_frames_per_launch_ = 0;
     double last_gemm_flop_ = 0.0;

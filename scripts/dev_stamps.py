@@ -5,7 +5,8 @@ out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["PVQ_STAMPS"] = out
 import numpy as np, torch
-import __graft_entry__ as g; g.build()
+import __graft_entry__ as g
+if not os.environ.get("PVQ_SKIP_BUILD"): g.build()
 import pitchvis_amd as P
 pp = P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 7, 36))
 v = P.Vqt(pp, 0); v.set_algo(2)
@@ -22,7 +23,8 @@ k, tr, st = (s[:, 1]-s[:, 0])*tick, (s[:, 2]-s[:, 1])*tick, (s[:, 3]-s[:, 2])*ti
 life = (s[:, 3]-s[:, 0])*tick
 print(f"workgroups {len(s)}  span {(s[:,3].max()-t0)*tick:.1f} us")
 sk, pw, rl, lp = (s[:, 4]-s[:, 1])*tick, (s[:, 5]-s[:, 4])*tick, (s[:, 6]-s[:, 5])*tick, (s[:, 2]-s[:, 6])*tick
-for name, a in (("k loop", k), ("tree", tr), (" skew", sk), (" Pwrite", pw), (" reglev", rl), (" ldslev", lp), ("store", st), ("life", life)):
+pro = (s[:, 7]-s[:, 0])*tick
+for name, a in ((" prolog", pro), ("k loop", k), ("tree", tr), (" skew", sk), (" Pwrite", pw), (" reglev", rl), (" ldslev", lp), ("store", st), ("life", life)):
     print(f"{name:7s} p10 {np.percentile(a,10):7.2f}  p50 {np.percentile(a,50):7.2f}  p90 {np.percentile(a,90):7.2f}  mean {a.mean():7.2f} us")
 # by fifths of the block index (groups are laid out one after the other: Nb = 64, 32, 16, 8, 4)
 n = len(s)

@@ -39,8 +39,8 @@ def test_status_strings_cover_every_status():
 
 @pytest.mark.parametrize("what,text", [("bad_alloc", "out of host memory"), ("length_error", "vector"), ("int", "unknown exception")])
 def test_exceptions_stop_at_the_abi(what, text):
-    """PVQ_TEST_THROW makes pvq_vqt_create throw inside its guarded body (the knob is read per call; a child process
-    keeps the environment of this one clean).  Without the barrier the child would die in std::terminate."""
+    """PVQ_TEST_THROW makes pvq_vqt_create of the DEVELOPER library (libpvq_dev.so; the product build has no such hook) throw inside
+    its guarded body (a child process keeps the environment of this one clean).  Without the barrier the child would die in std::terminate."""
     code = textwrap.dedent(f"""
         import ctypes as C, sys
         sys.path.insert(0, {ROOT!r})
@@ -51,7 +51,7 @@ def test_exceptions_stop_at_the_abi(what, text):
         st = L.pvq_vqt_create(C.byref(p), -1, C.byref(h), err)
         print("STATUS", st, "|", L.pvq_last_error().decode(), "|", bool(h.value))
     """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVQ_TEST_THROW=what), capture_output=True,
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVQ_TEST_THROW=what, PVQ_DEV_LIB="1"), capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1500:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("STATUS")][0]

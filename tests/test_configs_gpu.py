@@ -202,16 +202,16 @@ def test_unfused_fallback_stages_in_a_subprocess():
             assert err <= 1e-5, (name, err)
         print("UNFUSED_OK")
     """)
-    env = dict(os.environ, PVQ_NO_FUSE="1")
+    env = dict(os.environ, PVQ_NO_FUSE="1", PVQ_DEV_LIB="1")   # the developer library: the product build reads no environment
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "UNFUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_tile_shapes_bit_identical_in_subprocesses():
-    """Every tile shape of the hop-DFT + tree stage computes the same bits on every test geometry — same sums, same k order, same
-    tree levels: a frame's value must not depend on the tile that produced it.  256 x 32 (default), 160 x 32 and 128 x 32 rows
-    (PVQ_FUSED_BM), and the opt-in 16-column-tile kernel kept for measurement (PVQ_TILE16=1: blockdft_gemm_tree16).
+    """Both tile shapes of the hop-DFT + tree stage compute the same bits on every test geometry — same sums, same k order, same
+    tree levels: a frame's value must not depend on the tile that produced it.  256 x 32 rows (the product) and 128 x 32 rows
+    (PVQ_FUSED_BM=128, a knob of the developer library libpvq_dev.so), and the product library against the developer one.
     Child processes: the knobs are read once per process."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -240,13 +240,13 @@ def test_tile_shapes_bit_identical_in_subprocesses():
     """)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     res = {}
-    for tag, env in (("base", {}), ("tile16", {"PVQ_TILE16": "1"}), ("bm160", {"PVQ_FUSED_BM": "160"}), ("bm128", {"PVQ_FUSED_BM": "128"})):
+    for tag, env in (("base", {}), ("dev", {"PVQ_DEV_LIB": "1"}), ("bm128", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "128"})):
         f = os.path.join(root, "gpurun_out", f"forms_{tag}.npz")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0 and "FORM_OK" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = dict(np.load(f))
         os.remove(f)
-    for tag in ("tile16", "bm160", "bm128"):
+    for tag in ("dev", "bm128"):
         for k, a in res["base"].items():
             assert np.array_equal(a.view(np.uint32), res[tag][k].view(np.uint32)), (tag, k)
 

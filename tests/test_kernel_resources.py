@@ -4,6 +4,9 @@ vector registers per lane; one register more silently halves its occupancy (meas
 import os
 import re
 import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import pytest
 
@@ -35,7 +38,7 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
 
     for u in find("blockdft_gemm_treeILi256") + find("blockdft_gemm_treeILi128") + find("blockdft_gemm_tree_bf16x3ILi256"):
         # two 512-thread workgroups per CU; a few dwords of the tile set-up (stream-edge variant) may spill, the K loop bodies may not
-        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] <= 48, u
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] <= 64, u
     asm = tmp_path / "x.s"
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(asm)],
                        capture_output=True, text=True, timeout=600)
@@ -67,5 +70,45 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
             assert not any(re.match(r"\s+scratch_", l) for l in b), (name, "scratch access inside the K loop", b[0])
         checked += 1
     assert checked >= 3
+    # Every register written by a vector-memory load is covered by an s_waitcnt vmcnt before it is read, on every path, and every
+    # LDS-DMA before the next barrier (tests/isa_vmcnt.py: a dataflow over the compiled code).  The K loop's operand prefetch used to
+    # sit in a uniform `if`: not a correctness problem (the compiler then waits for MORE: vmcnt(4) / vmcnt(0) right after issuing
+    # the loads, i.e. no prefetch distance at all), but round 2's removed split-in-registers loop showed wrong rows with that shape and
+    # its cause was never found — so the shipped kernels' waits are now checked mechanically, and the hand-placed
+    # `s_waitcnt vmcnt(8)` of the fp32 kernel's prologue with them.
+    import isa_vmcnt
+    n_checked = 0
+    for name, lines in body.items():
+        if "blockdft_" not in name:
+            continue
+        bad = isa_vmcnt.check(lines)
+        assert not bad, (name, bad[:5])
+        n_checked += 1
+    assert n_checked >= 8
+    # the fp32 K loop keeps a whole double k group of operand loads in flight: after issuing the next group's 8 loads it must not wait
+    # for fewer than 8 outstanding (vmcnt(N), N >= 8) before its first MFMA
+    for name, lines in body.items():
+        if "blockdft_gemm_treeILi256" not in name:
+            continue
+        blocks, cur = [], []
+        for l in lines:
+            t = l.split(";")[0].strip()
+            if t.startswith(".LBB"):
+                blocks.append(cur)
+                cur = []
+            elif t:
+                cur.append(t)
+        blocks.append(cur)
+        hits = 0
+        for b in blocks:   # a K loop body: issues a double group of operand loads and MFMAs
+            loads = [i for i, t in enumerate(b) if t.startswith("buffer_load_dwordx4")]
+            if len(loads) < 8 or not any(t.startswith("v_mfma") for t in b):
+                continue
+            waits = [t for t in b[loads[7]:] if t.startswith("s_waitcnt") and "vmcnt" in t]
+            assert waits, b[:3]
+            n = int(re.search(r"vmcnt\((\d+)\)", waits[0]).group(1))
+            assert n >= 8, (name, waits[0])
+            hits += 1
+        assert hits >= 4, hits
     for u in find("blockdft_banddots8_dbILi8ELi4ELi260"):
         assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # 8 waves x 2 workgroups per CU

@@ -314,13 +314,18 @@ def test_blockdft_other_hops(hop):
 
 
 @pytest.mark.parametrize("hop", [64, 256])
-def test_blockdft_more_than_one_sub_batch(hop, monkeypatch):
+def test_blockdft_more_than_one_sub_batch(hop):
     """More frames than one sub-batch (the workspace, the stream rebasing and — at hop 64 — the partial-sum buffer of the
     two-level tree are reused per sub-batch): frames around the seam and at the end against the FFT path and the oracle.
-    Sub-batches are 131 072 frames by default; the developer knob (read per call) sets them to 65 536 here to keep the test small."""
-    monkeypatch.setenv("PVQ_CHUNK_FRAMES", "65536")
+    Sub-batches hold what the handle's workspace limit allows (131 072 frames at the default 1 GiB here); the limit is set
+    so that they hold 65 536 to keep the test small (test_configs_gpu.py runs a full-size shard at the default)."""
     pp, op = get_geom("bench_48k_252")
     v = P.Vqt.new(pp, 0)
+    v.set_algo(P.ALGO_BLOCKDFT)
+    warm = torch.zeros(hop * 64, device="cuda"); wdb_ = torch.empty((64, v.n_bins), device="cuda")
+    v.calculate_batch_db_device(warm, hop, 64, wdb_); torch.cuda.synchronize()   # builds the tables: the column count is known
+    per_frame = (v.blockdft_columns() + 32) * 8 * (2 if hop == 64 else 1)
+    v.set_workspace_limit(65536 * per_frame + per_frame)
     ov = O.OracleVqt(op)
     nf, n_lead = 65536 + 700, 5
     pcm = white_noise(n_lead + hop * nf, 99 + hop)
