@@ -54,7 +54,9 @@ SR, HOP = 48000.0, 256
 
 def _cpu_worker(args):
     """one oracle instance per worker over a disjoint frame range (train.rs:146-155 pattern)"""
-    seed, n_frames = args
+    seed, n_frames, lib = args
+    if lib:
+        os.environ["PVQ_ORACLE_LIB"] = lib   # (spawned worker: set before the oracle module loads its library)
     import numpy as np
     import oracle as O
     op = O.OracleParams(sr=SR, min_freq=55.0, octaves=7, buckets_per_octave=36)
@@ -71,34 +73,72 @@ def _cpu_worker(args):
     return time.perf_counter() - t0, n_peaks
 
 
+def _cpu_default_geometry_ms(n_frames=1500):
+    """one thread, the reference's DEFAULT geometry (22 050 Hz, 7 x 84 = 588 bins), transform only: the figure VQT_REVIEW.md:363-365
+    publishes for the Rust crate (0.091 ms per frame, rustfft, an unspecified desktop CPU)"""
+    import numpy as np
+    import oracle as O
+    ov = O.OracleVqt(O.OracleParams())
+    rng = np.random.default_rng(5)
+    pcm = ((rng.random(16384 + n_frames * HOP, dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ov.calculate_batch(pcm, HOP, n_frames, n_lead=16384)
+        best = min(best, time.perf_counter() - t0)
+    return best / n_frames * 1e3
+
+
 def cpu_baseline():
-    """The CPU restatement of the reference path (oracle, kind "port") on this host's cores,
-    bounded sample: `cores` workers x 2048 frames of the same workload (white noise, 48 kHz/252)."""
+    """The CPU restatement of the reference path (oracle, kind "port") on this host's cores, bounded sample: one worker per available
+    core x 2048 frames of the same workload (white noise, 48 kHz / 252 bins, transform + dB + peaks), SURVEY.md 8d: one thread, all
+    cores (-O2 as the reference's release profile), all cores at -O3 -march=native (courtesy figure), and the one-thread time per frame
+    at the reference's default geometry next to the 0.091 ms it publishes for its rustfft path."""
     import concurrent.futures as cf
     import multiprocessing as mp
+    import subprocess
     import oracle as O
     O.build()
+    orc_dir = os.path.join(ROOT, "oracle")
+    native = os.path.join(orc_dir, "liboracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", orc_dir, "liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        native = None
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
+    cores = max(1, min(avail, 256))   # every core this process may run on
     per = 2048
-    # single thread first
-    t1, _ = _cpu_worker((1000, per))
-    with cf.ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
-        list(ex.map(_cpu_worker, [(1, 8)] * cores))  # start the workers, load the library
-        t0 = time.perf_counter()
-        res = list(ex.map(_cpu_worker, [(2000 + i, per) for i in range(cores)]))
-        wall = time.perf_counter() - t0
+    t1, _ = _cpu_worker((1000, per, None))   # single thread first
+    ms_default = _cpu_default_geometry_ms()
+
+    def all_cores(lib):
+        with cf.ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
+            list(ex.map(_cpu_worker, [(1, 8, lib)] * cores))  # start the workers, load the library
+            t0 = time.perf_counter()
+            list(ex.map(_cpu_worker, [(2000 + i, per, lib) for i in range(cores)]))
+            return cores * per / (time.perf_counter() - t0)
+
+    v_o2 = all_cores(None)
+    v_native = all_cores(native) if native and os.path.exists(native) else None
     return {
-        "value": round(cores * per / wall, 1),
+        "value": round(v_o2, 1),
         "unit": "frames/s",
         "cores": cores,
+        "cores_available": avail,
         "kind": "port",
-        "sample": f"{cores} workers x {per} frames (hop 256, 48 kHz/252 bins, white noise), VQT+dB+peaks, "
-                  f"oracle/pvq_oracle.c -O2; 1 core: {per / t1:.0f} frames/s",
+        "sample": f"{cores} workers (every available core) x {per} frames (hop 256, 48 kHz/252 bins, white noise), VQT+dB+peaks, "
+                  f"oracle/pvq_oracle.c -O2 (the reference's release profile); 1 core: {per / t1:.0f} frames/s",
         "value_1core": round(per / t1, 1),
+        "value_native_O3": round(v_native, 1) if v_native else None,
+        "default_geometry_ms_per_frame_1core": round(ms_default, 4),
+        "reference_published_ms_per_frame": 0.091,
+        "note": "a floor for the reference's CPU path, not the reference: the port's scalar radix-2 real FFT (two stages per pass) is "
+                f"slower than rustfft's SIMD kernels — {ms_default:.3f} ms per frame here against the 0.091 ms VQT_REVIEW.md:363-365 "
+                "publishes at the same (default 22 050 Hz / 588-bin) geometry on an unspecified desktop CPU; value_native_O3: the same "
+                "source at -O3 -march=native on every core",
     }
 
 
@@ -136,9 +176,17 @@ def main():
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
-    entry.build()
+    # one rank at a time through build(): on a cold tree the first one compiles, the others find the stamped libraries (eight
+    # concurrent `make -B` into one directory otherwise)
+    import fcntl
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            entry.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     import pitchvis_amd as P
-    from pitchvis_amd.sharding import global_stream, local_pcm, plan_shard
+    from pitchvis_amd.sharding import plan_shard, stream_slice
 
     device_index = local_rank % max(torch.cuda.device_count(), 1)   # identity on an N-GPU node
     torch.cuda.set_device(device_index)
@@ -155,15 +203,13 @@ def main():
     vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
     assert vqt.n_bins == N_BINS
 
-    # this rank's shard of ONE world*F-frame stream: its hops plus the window-union halo that precedes them.  The stream
-    # is generated with the same seed on every rank (Philox: identical values on every device) and sliced, so the ranks
-    # really hold consecutive pieces of one signal, halos included.
+    # this rank's shard of ONE world*F-frame stream: its hops plus the window-union halo that precedes them.  The stream is a
+    # counter-based function of (seed, sample index), so every rank computes exactly its own piece — halo included — of one
+    # signal without materialising the rest (at N = 8 the whole stream is 1 GiB).
     F = args.frames or W["frames"]
     shard = plan_shard(world * F, HOP, vqt.window_union, rank, world)
     assert shard.n_frames == F
-    d_stream = global_stream(W["seed"], world * F * HOP, "cuda")
-    d_pcm = local_pcm(d_stream, shard)
-    del d_stream
+    d_pcm = stream_slice(W["seed"], shard.sample_begin, shard.sample_end, "cuda")
     torch.cuda.empty_cache()
     d_db = torch.empty((F, N_BINS), device="cuda", dtype=torch.float32)
     words = (N_BINS + 31) // 32
@@ -232,20 +278,28 @@ def main():
         # roofline.achieved / frac: what the dominant kernel's matrix instructions EXECUTE per second (their flop per
         # launch, counted by the library from its tile list: tiles x 256 rows x 64 real columns x depth x 2, padding
         # columns and recomputed rows included) over the kernel's whole duration (K loop + tree + store), against the
-        # dense fp32 MFMA peak.  It cannot exceed 1 and is reproducible from profiles/: SQ_INSTS_MFMA x 4096 / kernel time.
+        # dense fp32 MFMA peak.  It cannot exceed 1 and is reproducible from profiles/: SQ_INSTS_MFMA x 2048 (v_mfma_f32_16x16x4_f32) / kernel time.
         exec_tflops = None
         if dom[0] == "blockdft_gemm" and gemm_flop > 0:
             exec_tflops = gemm_flop / dom_s / 1e12
         achieved = exec_tflops if exec_tflops is not None else alg_tflops
-        traffic = None
+        # roofline.traffic: HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (scripts/collect_profiles.sh writes
+        # profiles/traffic_latest.json with the hash of the kernel sources it measured).  It is attached only when that hash is the
+        # hash of the library running now — a capture of an older build is named, not used.
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == fpl and tj.get("n_bins", 252) == N_BINS:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                now = open(os.path.join(ROOT, "pitchvis_amd", "lib", "libpvq.so.srchash")).read().strip()
+                for tj in json.load(open(tpath)).get("captures", []):
+                    if tj.get("kernel") == dom[0] and tj.get("frames_per_launch") == fpl and tj.get("n_bins") == N_BINS:
+                        if tj.get("srchash") == now:
+                            traffic = tj.get("hbm_bytes_per_launch")
+                            traffic_source = f"{tj.get('file')} (kernel sources {now[:12]}, the running build)"
+                        else:
+                            traffic_source = f"stale: {tj.get('file')} measured kernel sources {str(tj.get('srchash'))[:12]}, running {now[:12]}"
+            except Exception as e:   # a malformed capture file must not take the bench line down
+                traffic_source = f"unreadable: {e}"
         out = {
             "metric": "vqt_frames_per_sec",
             "value": round(value, 1),
@@ -268,6 +322,11 @@ def main():
                 "gemm_arith": ("fp32 operands as 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate "
                                "(error at fp32 rounding level, same parity bars)" if split else "fp32 MFMA v_mfma_f32_16x16x4_f32"),
                 "sharding": f"one stream, frames x{world}, halo {vqt.window_union - HOP} samples per shard, no collective",
+                # what the number was checked against: it travels with the headline
+                "parity": "HIP path vs oracle/pvq_oracle.c (a CPU restatement of the Rust path; the Rust binary cannot be built here: "
+                          "oracle unpinned vs the Rust binary); complex coefficients within 1e-5 of the frame peak, per-bin relative "
+                          "1e-5 for bins within 20 dB of the frame peak; peak index sets bit-identical on identical dB frames; "
+                          "find_peaks 0.1.5 distance-vs-prominence order unverified at 84 bins/octave (a no-op at this 36)",
             },
             "roofline": {
                 # the binding roof of this path is fp32 matrix arithmetic (dense fp32 MFMA peak = fp32 vector peak);
@@ -279,6 +338,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
                 "executed_flop_per_launch": gemm_flop if exec_tflops is not None else None,
                 # the FFT-route count of SURVEY 8d for the same frames, kept apart: the block-DFT path does not execute it

@@ -217,6 +217,30 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt *v, const float *d_pcm, size_t n
                                         uint32_t max_peaks, void *stream);
 
 
+/* ---- several devices, one stream ---------------------------------------------------------------------
+ * The reference's only data-parallel driver hands every rayon worker its own Vqt (pitchvis_train/src/train.rs:146-155:
+ * par_iter().map_init(|| Vqt::new(..), ..)).  The same shape here: one handle per worker (each on its own device, or
+ * several on one), ONE long stream split into contiguous frame ranges, each with a halo of window_union - hop samples of
+ * history, kernel tables replicated, no collective on the data path. */
+typedef struct pvq_shard {
+    uint64_t first_frame;   /* global index of the shard's first frame */
+    uint64_t n_frames;
+    uint64_t sample_begin;  /* first sample of the stream the shard must hold, counted from the stream's first hop */
+    uint64_t sample_end;    /* one past the last */
+    uint64_t n_lead;        /* samples of [sample_begin, sample_end) that are history before the shard's first hop */
+} pvq_shard;
+/* contiguous split of n_frames_total frames over `world` shards (the first n_frames_total % world take one more) */
+pvq_status pvq_plan_shard(uint64_t n_frames_total, uint64_t hop, uint64_t window_union, uint32_t rank, uint32_t world,
+                          pvq_shard *out);
+/* PCM -> dB frames -> peaks of one HOST stream on n_handles handles at once, one host thread each; the handles must have
+ * been created with the same parameters, and none may appear twice.  pcm: [n_lead + n_frames * hop]; outputs are host
+ * arrays laid out as for pvq_vqt_analyze_batch_device (peak outputs may be NULL; center and size go together).  Every
+ * output value equals, bit for bit, what one handle computes for the whole stream. */
+pvq_status pvq_vqt_analyze_batch_multi(pvq_vqt *const *handles, uint32_t n_handles, const float *pcm, size_t n_lead,
+                                       size_t hop, size_t n_frames, const pvq_analysis_params *a, float *out_db,
+                                       uint32_t *peak_mask, uint32_t *peak_count, float *center, float *size,
+                                       uint32_t max_peaks);
+
 /* ---- stateful per-stream analysis: AnalysisState (analysis.rs:119-410), host side ------------------
  * preprocess() is a recurrence over frames (bin EMAs, calmness EMAs and the scene calmness feed the
  * next frame's smoothing horizons: analysis.rs:295-319, calmness.rs:23-95), so it is sequential per

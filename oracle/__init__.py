@@ -13,14 +13,16 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# PVQ_ORACLE_LIB: another build of the same source (bench.py's cpu_baseline times oracle/liboracle_native.so, -O3 -march=native, as
+# a courtesy figure; tests/test_sanitize_cpu.py loads the ASan / UBSan build)
+_LIB_PATH = os.environ.get("PVQ_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (idempotent)."""
     src = os.path.join(_HERE, "pvq_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

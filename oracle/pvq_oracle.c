@@ -140,22 +140,36 @@ static void rfft_planned(const rfft_plan *p, const float *x, c32 *out)
     uint32_t n = p->n, h = n / 2;
     c32 *a = p->z;
     for (uint32_t i = 0; i < h; i++) { uint32_t r = p->rev[i]; a[r].re = x[2 * i]; a[r].im = x[2 * i + 1]; }
-    for (uint32_t len = 2; len <= h; len <<= 1) {
+    /* the radix-2 stages of fft_c32, two at a time: the four values of a pair of butterflies stay in registers between the two
+     * stages (same operations on the same operands in the same order: bit-identical to one stage per pass, half the passes over
+     * the array — the plain one-stage-per-pass loop made this port ~2x slower than the reference's rustfft, VQT_REVIEW.md:363) */
+#define ORC_BFLY(u, v, w) do { c32 t_; t_.re = (v).re * (w).re - (v).im * (w).im; t_.im = (v).re * (w).im + (v).im * (w).re; \
+        c32 u_ = (u); (u).re = u_.re + t_.re; (u).im = u_.im + t_.im; (v).re = u_.re - t_.re; (v).im = u_.im - t_.im; } while (0)
+    uint32_t len = 2;
+    for (; len * 2 <= h; len <<= 2) {
+        uint32_t half = len >> 1, step1 = h / len, len2 = len * 2, step2 = h / len2;
+        for (uint32_t i = 0; i < h; i += len2) {
+            for (uint32_t j = 0; j < half; j++) {
+                c32 w1 = p->tw[j * step1], w2a = p->tw[j * step2], w2b = p->tw[(j + half) * step2];
+                c32 a0 = a[i + j], a1 = a[i + j + half], a2 = a[i + j + len], a3 = a[i + j + len + half];
+                ORC_BFLY(a0, a1, w1);
+                ORC_BFLY(a2, a3, w1);
+                ORC_BFLY(a0, a2, w2a);
+                ORC_BFLY(a1, a3, w2b);
+                a[i + j] = a0; a[i + j + half] = a1; a[i + j + len] = a2; a[i + j + len + half] = a3;
+            }
+        }
+    }
+    for (; len <= h; len <<= 1) {   /* an odd number of stages: the last one alone */
         uint32_t half = len >> 1, step = h / len;
         for (uint32_t i = 0; i < h; i += len) {
             for (uint32_t j = 0; j < half; j++) {
                 c32 w = p->tw[j * step];
-                c32 u = a[i + j], v = a[i + j + half];
-                c32 t;
-                t.re = v.re * w.re - v.im * w.im;
-                t.im = v.re * w.im + v.im * w.re;
-                a[i + j].re = u.re + t.re;
-                a[i + j].im = u.im + t.im;
-                a[i + j + half].re = u.re - t.re;
-                a[i + j + half].im = u.im - t.im;
+                ORC_BFLY(a[i + j], a[i + j + half], w);
             }
         }
     }
+#undef ORC_BFLY
     for (uint32_t k = 0; k <= h; k++) {
         c32 za = a[k % h];
         c32 zb = a[(h - k) % h];

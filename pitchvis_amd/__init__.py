@@ -316,6 +316,32 @@ class Vqt:
                                                     _ptr(d_out_db), _ptr(d_peak_mask), _ptr(d_peak_count),
                                                     _ptr(d_center), _ptr(d_size), max_peaks, _stream_handle(stream)))
 
+    @staticmethod
+    def analyze_batch_multi(handles, pcm, hop: int, n_frames: int, n_lead: int = 0, analysis: Optional[AnalysisParameters] = None,
+                            max_peaks: int = 64, want_peaks: bool = True):
+        """One HOST stream on several handles at once (pvq_vqt_analyze_batch_multi: one host thread per handle, contiguous frame
+        ranges with halos, no collective): -> (db [n_frames][n_bins], mask, count, center, size) host arrays (peak arrays None
+        without want_peaks).  Bit for bit what one handle computes for the whole stream."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.size != n_lead + n_frames * hop:
+            raise ValueError("pcm must hold n_lead + n_frames * hop samples")
+        v0 = handles[0]
+        L = v0._L
+        nb, words = v0.n_bins, (v0.n_bins + 31) // 32
+        db = np.empty((n_frames, nb), np.float32)
+        mask = np.zeros((n_frames, words), np.uint32) if want_peaks else None
+        count = np.zeros(n_frames, np.uint32) if want_peaks else None
+        center = np.zeros((n_frames, max_peaks), np.float32) if want_peaks and max_peaks else None
+        size = np.zeros((n_frames, max_peaks), np.float32) if want_peaks and max_peaks else None
+        hs = (C.c_void_p * len(handles))(*[h._h for h in handles])
+        ap = (analysis or AnalysisParameters())._c()
+        fpt, upt = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        def p_(a, t):
+            return a.ctypes.data_as(t) if a is not None else None
+        _check(L.pvq_vqt_analyze_batch_multi(hs, len(handles), p_(pcm, fpt), n_lead, hop, n_frames, C.byref(ap), p_(db, fpt),
+                                             p_(mask, upt), p_(count, upt), p_(center, fpt), p_(size, fpt), max_peaks if center is not None else 0))
+        return db, mask, count, center, size
+
     def analyze_batch(self, db, analysis: Optional[AnalysisParameters] = None, max_peaks: int = 64):
         """Host dB frames [n_frames][n_bins] -> (mask u32 [n_frames][words], count, center, size)."""
         db = np.ascontiguousarray(db, np.float32)

@@ -17,7 +17,7 @@ EXPORTS = [
     "pvq_vqt_n_groups", "pvq_vqt_group_info", "pvq_vqt_group_csr", "pvq_vqt_filter_params",
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
-    "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
+    "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_plan_shard", "pvq_vqt_analyze_batch_multi", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
     "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_set_workspace_limit", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
     "pvq_analysis_state_update_vqt_smoothing_duration", "pvq_analysis_state_preprocess",
@@ -70,6 +70,11 @@ class CAnalysisParams(C.Structure):
         ("highest_bassnote", C.c_uint32),
         ("harmonic_threshold", C.c_float),
     ]
+
+
+class CShard(C.Structure):   # pvq_shard
+    _fields_ = [("first_frame", C.c_uint64), ("n_frames", C.c_uint64), ("sample_begin", C.c_uint64), ("sample_end", C.c_uint64),
+                ("n_lead", C.c_uint64)]
 
 
 class CAnalysisFullParams(C.Structure):
@@ -146,6 +151,10 @@ def load():
     L.pvq_vqt_analyze_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(CAnalysisParams),
                                                vp, vp, vp, vp, vp, C.c_uint32, vp]
     L.pvq_vqt_analyze_batch_device.restype = C.c_int
+    L.pvq_plan_shard.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(CShard)]; L.pvq_plan_shard.restype = C.c_int
+    L.pvq_vqt_analyze_batch_multi.argtypes = [C.POINTER(vp), C.c_uint32, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(CAnalysisParams),
+                                              fp, up, up, fp, fp, C.c_uint32]
+    L.pvq_vqt_analyze_batch_multi.restype = C.c_int
     L.pvq_vqt_set_profiling.argtypes = [vp, C.c_int]; L.pvq_vqt_set_profiling.restype = C.c_int
     L.pvq_vqt_last_kernel_ms.argtypes = [vp, fp, C.c_uint32]; L.pvq_vqt_last_kernel_ms.restype = C.c_uint32
     L.pvq_vqt_last_kernel_launches.argtypes = [vp, up, C.c_uint32]; L.pvq_vqt_last_kernel_launches.restype = C.c_uint32

@@ -12,6 +12,7 @@
 
 #include "analysis_host.hpp"
 #include "consumers_host.hpp"
+#include "multi_host.hpp"
 #include "vqt_engine.hpp"
 
 struct pvq_vqt {
@@ -399,6 +400,37 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt* v, const float* d_pcm, size_t n
         return v->impl->vqt_analyze_batch_device(d_pcm, n_lead, hop, n_frames, to_cpp(a), d_out_db, d_peak_mask,
                                                  d_peak_count, d_center, d_size, max_peaks,
                                                  static_cast<hipStream_t>(stream));
+    } catch (...) { return translate_exception(); }
+}
+
+pvq_status pvq_plan_shard(uint64_t n_frames_total, uint64_t hop, uint64_t window_union, uint32_t rank, uint32_t world, pvq_shard* out) {
+    try {
+        pvq::ShardPlan sp;
+        if (!out || !pvq::plan_shard(n_frames_total, hop, window_union, rank, world, &sp)) {
+            pvq::set_last_error("pvq_plan_shard: null output or rank >= world");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        out->first_frame = sp.first_frame;
+        out->n_frames = sp.n_frames;
+        out->sample_begin = sp.sample_begin;
+        out->sample_end = sp.sample_end;
+        out->n_lead = sp.n_lead;
+        return PVQ_OK;
+    } catch (...) { return translate_exception(); }
+}
+
+pvq_status pvq_vqt_analyze_batch_multi(pvq_vqt* const* handles, uint32_t n_handles, const float* pcm, size_t n_lead, size_t hop,
+                                       size_t n_frames, const pvq_analysis_params* a, float* out_db, uint32_t* peak_mask,
+                                       uint32_t* peak_count, float* center, float* size, uint32_t max_peaks) {
+    try {
+        if (!handles || n_handles == 0) return null_handle();
+        std::vector<pvq::Vqt*> hs(n_handles, nullptr);
+        for (uint32_t i = 0; i < n_handles; ++i) {
+            if (!handles[i]) return null_handle();
+            hs[i] = handles[i]->impl.get();
+        }
+        return pvq::analyze_batch_multi(hs.data(), n_handles, pcm, n_lead, hop, n_frames, to_cpp(a), out_db, peak_mask, peak_count,
+                                        center, size, max_peaks);
     } catch (...) { return translate_exception(); }
 }
 

@@ -102,7 +102,7 @@ struct BlockDftTables {
     __bf16* d_band_B3 = nullptr;   // per block and 8 columns: 3 planes x 64 lanes x 8 bf16 in v_mfma_f32_32x32x16_bf16 order
     // 8-bin blocks for the 16x16x4 MFMA form of the kernel product (fp32, 64-frame tiles)
     struct BandBlock* d_band8 = nullptr;
-    float* d_band_B8 = nullptr;    // per block and column pair: 64 floats in v_mfma_f32_16x16x4_f32 B-operand lane order
+    float* d_band_B4 = nullptr;    // per block and 4 columns: 64 x (Re coefficient, Im coefficient): the no-swap form
     int* d_band_list8 = nullptr;   // [8][band_per_wave8]
     int band_per_wave8 = 0;
     int* d_band_list = nullptr;    // [band_waves][band_per_wave]: per wave of a workgroup, the count and then the blocks it walks
@@ -132,7 +132,7 @@ void free_blockdft_tables(BlockDftTables* t) {
     if (t->d_band) (void)hipFree(t->d_band);
     if (t->d_band_B) (void)hipFree(t->d_band_B);
     if (t->d_band8) (void)hipFree(t->d_band8);
-    if (t->d_band_B8) (void)hipFree(t->d_band_B8);
+    if (t->d_band_B4) (void)hipFree(t->d_band_B4);
     if (t->d_band_list8) (void)hipFree(t->d_band_list8);
     if (t->d_band_B3) (void)hipFree(t->d_band_B3);
     if (t->d_band_list) (void)hipFree(t->d_band_list);
@@ -361,8 +361,9 @@ __device__ __forceinline__ void fused_store_x(float* smem, const FusedTile& t, c
     if (j < t.S && f < t.nfr) {
         // windows of more than 64 blocks: 64-block partial sums go to Y, blockdft_tree_finish adds the last levels
         float2* dst = (t.G.nb > t.G.nb_f ? a.Y : a.X) + ((size_t)(f >> 6) * a.xcp + t.nt * CB_C) * 64 + (f & 63);
+        const int ncv = t.G.n_cols - t.ntl * CB_C < CB_C ? t.G.n_cols - t.ntl * CB_C : CB_C;   // the tile's real columns: the padding of a group's last tile is never read with a non-zero coefficient and never written (X starts out zeroed)
 #pragma unroll 4
-        for (int cc = tid / BM; cc < CB_C; cc += 2) {   // streamed out (non-temporal): the kernel-product stage that reads X back runs 5 % faster for it
+        for (int cc = tid / BM; cc < ncv; cc += 2) {   // streamed out (non-temporal): the kernel-product stage that reads X back runs 5 % faster for it
             const float2 val = A[j][cc];
             __builtin_nontemporal_store((f32x2){val.x, val.y}, reinterpret_cast<f32x2*>(&dst[cc * 64]));   // one 8-byte store
         }
@@ -933,14 +934,15 @@ struct FinishArgs {
     int xcp;
     int n_frames;
     int col0;          // first X column of the group
-    int n_cols;        // columns of the group (padded to its tiles)
+    int n_cols;        // columns of the group (padded to its tiles): the twiddle table's row stride
+    int n_real;        // columns of the group that exist (the padding is neither written by the fused kernel nor combined here)
     int levels_f, levels;
     const float2* tw;  // the group's combine twiddles: [levels][n_cols]
 };
 __global__ __launch_bounds__(256) void blockdft_tree_finish(FinishArgs a) {
     const int fr = threadIdx.x & 63, cc = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int tile = blockIdx.x;
-    if (cc >= a.n_cols || tile * 64 + fr >= a.n_frames) return;
+    if (cc >= a.n_real || tile * 64 + fr >= a.n_frames) return;
     const int col = a.col0 + cc;
     const int nq = 1 << (a.levels - a.levels_f);   // 2 or 4
     float2 v[4];
@@ -1322,84 +1324,84 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
     }
 }
 
-// 16x16x4 form of the fp32 kernel product (64-frame tiles, up to 256 bins): blocks of 8 bins, so a block walks the union
-// of only 8 rows' columns (about 35 instead of 57) — the same products in 39 % fewer matrix-pipe cycles, which is what
-// bounds the 32x32x2 form's block phase.  A lane loads (Re, Im) of its frame for a pair of spectrum columns; two
-// v_permlane32_swap + two v_permlane16_swap transpose the four registers (Re c, Im c, Re c+1, Im c+1 over 64 frames) into
-// the A operands of the four 16-frame tiles (k = 0..3 in lane rows 0..3), one v_mfma_f32_16x16x4_f32 each; the B operand
-// of a column pair is one float per lane.  (Loading the A operands in lane order instead — four strided dword loads per
-// pair, no swaps — was measured slower: 185 vs 134 us; the stage is bound by vector-memory instructions, not by the
-// matrix pipe or by latency: ring depths 3 / 4 / 6 time the same.)  C layout: column n = lane & 15 (part = n >> 3, bin row = n & 7), frame =
-// 16 m + 4 (lane >> 4) + r; the im column's value reaches the re column's lane with a DPP row rotate.
+// 16x16x4 form of the fp32 kernel product (64-frame tiles, up to 304 bins: the default): blocks of 8 bins, so a block walks the union
+// of only 8 rows' columns (about 35 instead of 57) — the same products in 39 % fewer matrix-pipe cycles than the 32x32x2 form above.
+// Its first version (round 2) fetched 8 bytes per lane — one complex value of one column — and turned four such registers into the
+// MFMA operands of the four 16-frame tiles with two v_permlane32_swap + two v_permlane16_swap per column pair: 133-150 us per
+// 65 536 frames, bound by its vector-memory instructions.  This form needs NO lane swaps and issues half the loads (16 bytes each):
+// 113-125 us on the same boxes.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int NW, int NS, int LDB>   // LDB: row stride of the LDS tile (4 mod 16, >= bins)
-__global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArgs a) {
+// Lane (i = lane & 15, kq = lane >> 4) loads 16 bytes of column c + kq: (Re, Im) of the frame PAIR 16 u + i of the tile (frames 32 u + 2 i and + 1), and each
+// of its four registers IS an A operand of v_mfma_f32_16x16x4_f32 as it stands: the k slots of an MFMA are the four columns
+// c .. c + 3 (Re parts for register 0 / 2, Im parts for 1 / 3), its rows the 16 even (registers 0, 1) or odd (2, 3) frames of the
+// half tile u; the B operand of lane (n, kq) is the coefficient of column c + kq for output n (n < 8: re of bin row n, else im),
+// one register for the Re parts and one for the Im parts.  Per four columns: two 16-byte X loads and one 8-byte B load per lane
+// instead of four 8-byte loads + one, eight MFMAs as before, no swaps.  C layout: output n = lane & 15, frame 32 u + 2 (4 (lane >> 4) + r) + p.
+template <int NW, int NS, int LDB, int NU>   // LDB: row stride of the LDS tile (4 mod 16, >= bins); NU: half tiles of 32 frames per workgroup (2: a whole X tile; 1 — half a tile, 4 waves, four workgroups per CU — was measured slower: 141-150 against 121 us)
+__global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_banddots4c_db(BandArgs a) {
     const int stamp_slot = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][LDB]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f0 = blockIdx.x * 64;
+    const int f0 = blockIdx.x * (32 * NU);
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
-    const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride;
+    const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // (a half-tile workgroup starts at frame pair 16 of its tile)
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
     const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
+    const int n = lane & 15, kq = lane >> 4;
     const float* xa = nullptr;
     const float2* bp = nullptr;
-    float2 av[NS][BD8_KU];
+    f32x4 av[NS][NU];
     float2 bv[NS];
-    static_assert(BD8_KU == 4, "a stage is two column pairs");
-    auto fetch = [&](int s, int c) {
+    auto fetch = [&](int s, int c) {   // stage: columns c .. c + 3 of the block
         bv[s] = bp[(size_t)(c / 4) * 64];
 #pragma unroll
-        for (int u = 0; u < BD8_KU; ++u) av[s][u] = *reinterpret_cast<const float2*>(xa + (size_t)(c + u) * col_stride);
+        for (int u = 0; u < NU; ++u) av[s][u] = *reinterpret_cast<const f32x4*>(xa + (size_t)c * col_stride + u * 64);
     };
     auto open_block = [&](const BandBlock& blk) {
-        xa = xtile + (size_t)blk.x0 * col_stride + lane * 2;
-        bp = reinterpret_cast<const float2*>(a.B + (size_t)blk.boff * 64) + lane;
+        xa = xtile + (size_t)(blk.x0 + kq) * col_stride + n * 4;
+        bp = reinterpret_cast<const float2*>(a.B) + (size_t)blk.boff3 * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < NS - 1; ++s) fetch(s, s * BD8_KU);
+        for (int s = 0; s < NS - 1; ++s) fetch(s, s * 4);
     };
     BandBlock blk{};
     if (n_blocks > 0) {
         blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[1])];
         open_block(blk);
     }
-    const int n = lane & 15, fr_lo = 4 * (lane >> 4);
     for (int bi = 0; bi < n_blocks; ++bi) {
-        f32x4v acc[4];
+        f32x4v acc[NU][2];   // [half tile u][p: even / odd frames]
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[m][q] = 0.0f;
-        auto mul = [&](int s) {
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int u = 0; u < BD8_KU / 2; ++u) {
-                float r0 = av[s][2 * u].x, r1 = av[s][2 * u].y, r2 = av[s][2 * u + 1].x, r3 = av[s][2 * u + 1].y;
-                permlane32_swap(r0, r2);
-                permlane32_swap(r1, r3);
-                permlane16_swap(r0, r1);
-                permlane16_swap(r2, r3);
-                const float b = u ? bv[s].y : bv[s].x;
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r0, b, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r1, b, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(r2, b, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(r3, b, acc[3], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[u][p][q] = 0.0f;
+        auto mul = [&](int s) {   // independent accumulators between two uses of one
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {   // Re parts of the four columns, then Im parts
+                const float b = part ? bv[s].y : bv[s].x;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][u][part], b, acc[u][0], 0, 0, 0);
+                    acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][u][2 + part], b, acc[u][1], 0, 0, 0);
+                }
             }
         };
         const int kb = __builtin_amdgcn_readfirstlane(blk.kb);
-        const int kb_full = kb - kb % (NS * BD8_KU);
+        const int kb_full = kb - kb % (NS * 4);
         int c = 0;
-        for (; c < kb_full; c += NS * BD8_KU) {   // steady state: no branches, exact load counting
+        for (; c < kb_full; c += NS * 4) {   // steady state: no branches, exact load counting
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                fetch((s + NS - 1) % NS, c + (s + NS - 1) * BD8_KU);
+                fetch((s + NS - 1) % NS, c + (s + NS - 1) * 4);
                 mul(s);
-                __builtin_amdgcn_sched_barrier(0);   // keep a stage's lane swaps (and the waits on its operands) inside the stage
+                __builtin_amdgcn_sched_barrier(0);   // keep the waits on a stage's operands inside the stage
             }
         }
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)          // remainder: the operands are already in flight
-            if (c + s * BD8_KU < kb) mul(s);
+            if (c + s * 4 < kb) mul(s);
         const int bin0 = blk.bin0, nrows = blk.nrows;
         if (bi + 1 < n_blocks) {                      // the next block's first operands fly during the write-out
             blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
@@ -1408,32 +1410,34 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots8_db(BandArg
         const bool mine = n < nrows;                  // re columns of live rows
         const int bin = bin0 + n;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float im[4];
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {   // row_ror:8: lane n <- lane n ^ 8 (through a scalar copy: the DPP of a vector element was seen merged across q)
-                const float re_q = acc[m][q];
-                im[q] = PVQ_DPP(re_q, 0x128);
-            }
-            if (mine) {
+            for (int p = 0; p < 2; ++p) {
+                float im[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dbs[(16 * m + fr_lo + q) * LDB + bin] = acc[m][q] * acc[m][q] + im[q] * im[q];
-                if (a.out_cplx) {
-                    int row_stride = a.n_bins;
-                    asm volatile("" : "+s"(row_stride));
+                for (int q = 0; q < 4; ++q) {   // row_ror:8: lane n <- lane n ^ 8 (through a scalar copy: the DPP of a vector element was seen merged across q)
+                    const float re_q = acc[u][p][q];
+                    im[q] = PVQ_DPP(re_q, 0x128);
+                }
+                if (mine) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int fr = 16 * m + fr_lo + q;
-                        if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * row_stride + bin] = make_float2(acc[m][q], im[q]);
+                    for (int q = 0; q < 4; ++q) dbs[(32 * u + 8 * kq + 2 * q + p) * LDB + bin] = acc[u][p][q] * acc[u][p][q] + im[q] * im[q];
+                    if (a.out_cplx) {
+                        int row_stride = a.n_bins;
+                        asm volatile("" : "+s"(row_stride));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int fr = 32 * u + 8 * kq + 2 * q + p;
+                            if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * row_stride + bin] = make_float2(acc[u][p][q], im[q]);
+                        }
                     }
                 }
             }
-        }
     }
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<2, NW, LDB>(dbs, a, f0, wave, lane);
+    band_finish<NU, NW, LDB>(dbs, a, f0, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1765,7 +1769,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     // products.  B operand of a column pair, lane l (n = l & 15: part = n >> 3, row = n & 7; k = l >> 4: column k >> 1 of
     // the pair, k & 1 = 0 multiplies Re X, 1 multiplies Im X).
     std::vector<BandBlock> band8;
-    std::vector<float> band_B8;
+    std::vector<float> band_B8, band_B4;
     for (size_t g = 0; g < groups.size(); ++g) {
         const CsrMatrix& A = groups[g].filter_bank;
         const CsrMatrix& Bm = groups[g].negative_filter_bank;
@@ -1828,9 +1832,22 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                         at8(cc, 1, 1, row) += -wr;
                     }
             }
+            // the same block in the order of blockdft_banddots4c_db: per 4 columns (group gq) and lane (kq = column of the group, n = part * 8 + row)
+            // a float2 (coefficient of Re X, coefficient of Im X)
+            bb.boff3 = (int)(band_B4.size() / 128);   // in groups of 4 columns
+            band_B4.resize(band_B4.size() + (size_t)(bb.kb / 4) * 128, 0.0f);
+            {
+                float* B4 = band_B4.data() + (size_t)bb.boff3 * 128;
+                for (int cc = 0; cc < bb.kb; ++cc)
+                    for (int kk = 0; kk < 2; ++kk)
+                        for (int part = 0; part < 2; ++part)
+                            for (int row = 0; row < 8; ++row)
+                                B4[((size_t)(cc >> 2) * 64 + (cc & 3) * 16 + part * 8 + row) * 2 + kk] = at8(cc, kk, part, row);
+            }
             band8.push_back(bb);
         }
     }
+    band_B4.resize(band_B4.size() + (size_t)8 * 128, 0.0f);   // the prefetch of the last block runs on past it
     band_B8.resize(band_B8.size() + (size_t)8 * (BD8_KU / 2) * 64, 0.0f);   // the prefetch of the last block runs on past it
     t->band_per_wave8 = (int)band8.size() + 2;
     std::vector<int> band_list8((size_t)8 * t->band_per_wave8, 0);
@@ -1910,7 +1927,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
     t->h_E = E;  // kept for the lazily built bf16 planes
     bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
-              up(&t->d_band_B8, band_B8) && up(&t->d_band_list8, band_list8) &&
+              up(&t->d_band_B4, band_B4) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
               up(&t->d_E16, E16);
     if (!ok) {
@@ -2138,10 +2155,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     fin.n_frames = (int)nf;
                     fin.col0 = G.tile0 * CB_C;
                     fin.n_cols = G.n_tiles * CB_C;
+                    fin.n_real = G.n_cols;
                     fin.levels_f = G.levels_f;
                     fin.levels = G.levels;
                     fin.tw = t->d_comb_tw + G.tw_off;
-                    hipLaunchKernelGGL(blockdft_tree_finish, dim3((unsigned)((nf + 63) / 64), (unsigned)((fin.n_cols + 3) / 4)), dim3(256), 0,
+                    hipLaunchKernelGGL(blockdft_tree_finish, dim3((unsigned)((nf + 63) / 64), (unsigned)((fin.n_real + 3) / 4)), dim3(256), 0,
                                        stream, fin);
                 }
                 slot_end(SLOT_BLOCKDFT_COMBINE, stream);
@@ -2225,18 +2243,13 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 hipLaunchKernelGGL((blockdft_banddots_db<2, 8>), grid, dim3(512), lds, stream, da);
             } else {   // 8-bin blocks, 16x16x4 MFMAs
                 da.blocks = t->d_band8;
-                da.B = t->d_band_B8;
                 da.list = t->d_band_list8;
                 da.per_wave = t->band_per_wave8;
-                static const int ns_env = dev_knob("PVQ_DOTS_NS", 0);   // operand ring depth
+                da.B = t->d_band_B4;
                 if (wide308)
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS, BAND_LDB3>), grid, dim3(512), lds, stream, da);
-                else if (ns_env == 3)
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 3, BAND_LDB2>), grid, dim3(512), lds, stream, da);
-                else if (ns_env == 6)
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, 6, BAND_LDB2>), grid, dim3(512), lds, stream, da);
+                    hipLaunchKernelGGL((blockdft_banddots4c_db<8, BD8_NS, BAND_LDB3, 2>), grid, dim3(512), lds, stream, da);
                 else
-                    hipLaunchKernelGGL((blockdft_banddots8_db<8, BD8_NS, BAND_LDB2>), grid, dim3(512), lds, stream, da);
+                    hipLaunchKernelGGL((blockdft_banddots4c_db<8, BD8_NS, BAND_LDB2, 2>), grid, dim3(512), lds, stream, da);
             }
         } else {
             if (dots_split) {

@@ -16,6 +16,7 @@
 #include "vqt_engine.hpp"
 
 #include <algorithm>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1120,6 +1121,131 @@ pvq_status Vqt::analyze_batch(const float* db, size_t n_frames, const AnalysisPa
     if (peak_count) PVQ_HIP(hipMemcpy(peak_count, d_cnt, b_cnt, hipMemcpyDeviceToHost));
     if (center && max_peaks) PVQ_HIP(hipMemcpy(center, d_ctr, b_pk, hipMemcpyDeviceToHost));
     if (size && max_peaks) PVQ_HIP(hipMemcpy(size, d_sz, b_pk, hipMemcpyDeviceToHost));
+    return PVQ_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// several handles, one host stream (multi-device driver)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {   // scoped device allocation
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+}  // namespace
+
+pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const float* pcm, size_t n_lead, size_t hop, size_t n_frames,
+                               const AnalysisParameters& ap, float* out_db, uint32_t* peak_mask, uint32_t* peak_count, float* center,
+                               float* size, uint32_t max_peaks) {
+    if (!handles || n_handles == 0) {
+        set_last_error("analyze_batch_multi: no handles");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    if (n_frames == 0) return PVQ_OK;
+    if (!pcm || !out_db || hop == 0) {
+        set_last_error("analyze_batch_multi: null pointer or zero hop");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    if ((center != nullptr) != (size != nullptr) || (center && max_peaks == 0)) {
+        set_last_error("analyze_batch_multi: center and size go together, with max_peaks > 0");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    for (uint32_t g = 0; g < n_handles; ++g) {
+        if (!handles[g]) {
+            set_last_error("analyze_batch_multi: null handle");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        if (!handles[g]->has_device()) {
+            set_last_error("handle was created without a device; there is no CPU fallback");
+            return PVQ_ERR_NO_DEVICE;
+        }
+        for (uint32_t h = 0; h < g; ++h)
+            if (handles[h] == handles[g]) {
+                set_last_error("analyze_batch_multi: a handle is exclusive to one worker; the same handle was passed twice");
+                return PVQ_ERR_INVALID_ARG;
+            }
+        const VqtParameters &p0 = handles[0]->params(), &pg = handles[g]->params();
+        if (std::memcmp(&p0, &pg, sizeof(VqtParameters)) != 0) {
+            set_last_error("analyze_batch_multi: the handles were created with different parameters");
+            return PVQ_ERR_INVALID_ARG;
+        }
+    }
+    const size_t nb = handles[0]->n_bins(), words = (nb + 31) / 32;
+    const size_t wu = handles[0]->plan().window_union;
+    const bool want_peaks = peak_mask || peak_count || center;
+    std::vector<pvq_status> status(n_handles, PVQ_OK);
+    std::vector<std::string> message(n_handles);
+    auto work = [&](uint32_t g) {
+        // the worker's error text is thread-local: hand it back with the status
+        auto fail = [&](pvq_status st, const std::string& msg) {
+            status[g] = st;
+            message[g] = msg;
+        };
+        try {
+            ShardPlan sh;
+            if (!plan_shard(n_frames, hop, wu, g, n_handles, &sh)) return fail(PVQ_ERR_INTERNAL, "plan_shard failed");
+            if (sh.n_frames == 0) return;
+            // plan_shard counts samples from the stream's first hop; the caller's array starts n_lead samples earlier, and a shard's
+            // halo may reach into that history
+            const size_t hop_begin = n_lead + (size_t)sh.first_frame * hop;
+            const size_t halo = wu > hop ? wu - hop : 0;
+            const size_t begin = hop_begin > halo ? hop_begin - halo : 0;
+            const size_t lead = hop_begin - begin, n_samp = lead + (size_t)sh.n_frames * hop, nf = (size_t)sh.n_frames;
+            Vqt* v = handles[g];
+            if (hipSetDevice(v->device()) != hipSuccess) return fail(PVQ_ERR_DEVICE, "hipSetDevice failed");
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(PVQ_ERR_DEVICE, "hipStreamCreate failed");
+            struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+            DevBuf d_pcm, d_db, d_mask, d_count, d_center, d_size;
+            bool ok = d_pcm.alloc(n_samp * 4) == hipSuccess && d_db.alloc(nf * nb * 4) == hipSuccess;
+            if (ok && want_peaks) ok = d_mask.alloc(nf * words * 4) == hipSuccess && d_count.alloc(nf * 4) == hipSuccess;
+            if (ok && center) ok = d_center.alloc(nf * max_peaks * 4) == hipSuccess && d_size.alloc(nf * max_peaks * 4) == hipSuccess;
+            if (!ok) return fail(PVQ_ERR_DEVICE, "hipMalloc failed for a shard's buffers");
+            if (hipMemcpyAsync(d_pcm.p, pcm + begin, n_samp * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(PVQ_ERR_DEVICE, "upload failed");
+            if (center) {   // entries beyond a frame's count are left as the caller passed them: start from the caller's contents
+                const size_t off = (size_t)sh.first_frame * max_peaks;
+                if (hipMemcpyAsync(d_center.p, center + off, nf * max_peaks * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(d_size.p, size + off, nf * max_peaks * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+                    return fail(PVQ_ERR_DEVICE, "upload failed");
+            }
+            pvq_status rs;
+            if (want_peaks)
+                rs = v->vqt_analyze_batch_device(d_pcm.as<float>(), lead, hop, nf, ap, d_db.as<float>(), d_mask.as<uint32_t>(), d_count.as<uint32_t>(),
+                                                 center ? d_center.as<float>() : nullptr, center ? d_size.as<float>() : nullptr, max_peaks, st);
+            else
+                rs = v->calculate_batch_db_device(d_pcm.as<float>(), lead, hop, nf, d_db.as<float>(), nullptr, st);
+            if (rs != PVQ_OK) return fail(rs, get_last_error());
+            const size_t f0 = (size_t)sh.first_frame;
+            bool cp = hipMemcpyAsync(out_db + f0 * nb, d_db.p, nf * nb * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+            if (cp && peak_mask) cp = hipMemcpyAsync(peak_mask + f0 * words, d_mask.p, nf * words * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+            if (cp && peak_count) cp = hipMemcpyAsync(peak_count + f0, d_count.p, nf * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+            if (cp && center)
+                cp = hipMemcpyAsync(center + f0 * max_peaks, d_center.p, nf * max_peaks * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipMemcpyAsync(size + f0 * max_peaks, d_size.p, nf * max_peaks * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+            if (!cp || hipStreamSynchronize(st) != hipSuccess) return fail(PVQ_ERR_DEVICE, "download failed");
+            rs = v->input_status(st);
+            if (rs != PVQ_OK) return fail(rs, get_last_error());
+        } catch (const std::bad_alloc&) {
+            fail(PVQ_ERR_INTERNAL, "out of host memory");
+        } catch (const std::exception& e) {
+            fail(PVQ_ERR_INTERNAL, e.what());
+        } catch (...) {
+            fail(PVQ_ERR_INTERNAL, "unknown exception in a shard worker");
+        }
+    };
+    std::vector<std::thread> threads;
+    threads.reserve(n_handles);
+    for (uint32_t g = 1; g < n_handles; ++g) threads.emplace_back(work, g);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (uint32_t g = 0; g < n_handles; ++g)
+        if (status[g] != PVQ_OK) {
+            set_last_error("shard " + std::to_string(g) + ": " + message[g]);
+            return status[g];
+        }
     return PVQ_OK;
 }
 

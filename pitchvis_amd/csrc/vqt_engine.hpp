@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pvq.h"
+#include "multi_host.hpp"
 #include "vqt_host.hpp"
 
 namespace pvq {
@@ -147,6 +148,14 @@ class Vqt {
     void* ws_misc_ = nullptr; size_t ws_misc_cap_ = 0;
     void* ws_flags_ = nullptr; size_t ws_flags_cap_ = 0;  // per-frame redo flags of the peak kernels
 };
+
+// One stream of host PCM analysed on several handles at once (one host thread per handle; handles may sit on different devices
+// or share one): contiguous frame ranges with a halo of window_union - hop samples (multi_host.hpp), no collective, outputs written
+// straight into the caller's host arrays.  Mirrors the only data-parallel driver of the reference — rayon's map_init with one Vqt
+// per worker, pitchvis_train/src/train.rs:146-155 — for ONE long stream.  Any of the peak outputs may be null.
+pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const float* pcm, size_t n_lead, size_t hop, size_t n_frames,
+                               const AnalysisParameters& a, float* out_db, uint32_t* peak_mask, uint32_t* peak_count, float* center,
+                               float* size, uint32_t max_peaks);
 
 void set_last_error(const std::string& s);
 void set_last_error_noexcept(const char* s) noexcept;   // for exception handlers: never throws (drops the text if it cannot be stored)

@@ -18,25 +18,41 @@ class Shard:
 
 
 def plan_shard(n_frames_total: int, hop: int, window_union: int, rank: int, world: int) -> Shard:
-    """Contiguous split; the first `n_frames_total % world` ranks take one extra frame."""
+    """Contiguous split; the first `n_frames_total % world` ranks take one extra frame.  The arithmetic lives in the library
+    (pvq_plan_shard, pitchvis_amd/csrc/multi_host.cpp): the multi-device driver behind the C ABI and this Python face of it
+    (torch.distributed ranks) cut a stream in the same places."""
+    import ctypes as C
+    from . import _lib
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
-    base, extra = divmod(n_frames_total, world)
-    n = base + (1 if rank < extra else 0)
-    first = rank * base + min(rank, extra)
-    hop_begin = first * hop                      # first new sample of this shard
-    halo = max(window_union - hop, 0)            # samples before hop_begin its first frame reads
-    begin = max(hop_begin - halo, 0)
-    return Shard(first, n, begin, hop_begin + n * hop, hop_begin - begin)
+    out = _lib.CShard()
+    st = _lib.load().pvq_plan_shard(n_frames_total, hop, window_union, rank, world, C.byref(out))
+    if st != 0:
+        raise ValueError("bad rank/world")
+    return Shard(int(out.first_frame), int(out.n_frames), int(out.sample_begin), int(out.sample_end), int(out.n_lead))
+
+
+def stream_slice(seed: int, begin: int, end: int, device="cuda"):
+    """Samples [begin, end) of the synthetic benchmark stream: white noise uniform in [-0.25, 0.25), fp32, a counter-based function of
+    (seed, sample index) — splitmix64 of the index, its top 24 bits as the uniform — so that any rank computes exactly its own piece
+    of ONE signal (halo included) without generating the rest, identically on every device type."""
+    import torch
+    i = torch.arange(begin, end, dtype=torch.int64, device=device)
+    mask = lambda n: (1 << n) - 1   # noqa: E731  (logical right shifts on two's-complement int64)
+    def to_i64(x):
+        x &= (1 << 64) - 1
+        return x - (1 << 64) if x >= (1 << 63) else x
+    z = i * to_i64(0x9E3779B97F4A7C15) + to_i64((seed + 1) * 0xD1B54A32D192ED03)
+    z = (z ^ ((z >> 30) & mask(34))) * to_i64(0xBF58476D1CE4E5B9)
+    z = (z ^ ((z >> 27) & mask(37))) * to_i64(0x94D049BB133111EB)
+    z = z ^ ((z >> 31) & mask(33))
+    u = ((z >> 40) & mask(24)).to(torch.float32) * (1.0 / (1 << 24))   # [0, 1), exact in fp32
+    return (u - 0.5) * 0.5
 
 
 def global_stream(seed: int, n_samples: int, device="cuda"):
-    """The synthetic benchmark stream: white noise uniform in [-0.25, 0.25), fp32.  Same seed => same values on every
-    rank (one Philox stream per device type), so that ranks slicing it hold consecutive pieces of ONE signal."""
-    import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    return (torch.rand(n_samples, device=device, generator=g) - 0.5) * 0.5
+    """The whole synthetic benchmark stream (tests; the ranks of bench.py take stream_slice of their own piece)."""
+    return stream_slice(seed, 0, n_samples, device)
 
 
 def local_pcm(stream, shard: Shard):

@@ -1,41 +1,84 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) from the repo root: bench line, rocprofv3 kernel stats, HBM PMC passes.
-# usage: scripts/collect_profiles.sh <tag>     -> files under gpurun_out/<tag>_*
+# Run on the GPU box (via gpurun) from the repo root: bench lines (configs[1] and [2]), rocprofv3 kernel stats, HBM PMC passes
+# (FETCH_SIZE / WRITE_SIZE in separate passes), SQ counters of the dominant kernels.  Writes gpurun_out/<tag>_* and
+# gpurun_out/traffic_latest.json (the captures bench.py attaches as roofline.traffic, stamped with the hash of the kernel sources
+# they were measured on: bench.py refuses a capture whose hash is not the running library's).
+# usage: scripts/collect_profiles.sh <tag>
 set -e
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 $ROOT/bench.py --steps 10 --warmup 3 --config 2 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2>> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
+# (the program goes directly after `--`: no env / bash -c hop under rocprofv3)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$c.log 2>&1
+for cfg in 1 2; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc${cfg}_$c -- python3 $ROOT/bench.py --steps 3 --warmup 1 --config $cfg --no-cpu-baseline > $OUT/${TAG}_pmc${cfg}_$c.log 2>&1
+  done
+done
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM" \
+           "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_sq$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_sq$i.log 2>&1 || echo "SQ pass $i failed"
 done
 cd $ROOT
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, os
 tag = "$TAG"
-rows = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"gpurun_out/{tag}_pmc_{c}/*/*counter_collection.csv")[0]
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "pvq::" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        rows.setdefault(k, {})[c] = sum(v) / len(v)
-with open(f"gpurun_out/{tag}_pmc_traffic.csv", "w") as f:
-    f.write("kernel,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean,hbm_bytes_per_launch(2*FETCH+WRITE)*1024\n")
-    for k, v in rows.items():
-        fe, wr = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
-        f.write(f"\"{k}\",{fe:.1f},{wr:.1f},{(2*fe+wr)*1024:.0f}\n")
+srchash = open("pitchvis_amd/lib/libpvq.so.srchash").read().strip()
+SLOT = {"blockdft_gemm_tree": "blockdft_gemm", "blockdft_banddots": "blockdft_dots_db", "peaks_frames_lean": "peaks_frames"}
+captures = []
+for cfg, n_bins, fpl in ((1, 252, 65536), (2, 288, 131072)):
+    rows = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        fs = glob.glob(f"gpurun_out/{tag}_pmc{cfg}_{c}/*/*counter_collection.csv")
+        if not fs:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if "pvq::" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            rows.setdefault(k, {})[c] = sum(v) / len(v)
+    name = f"gpurun_out/{tag}_pmc_traffic{'' if cfg == 1 else '_config2'}.csv"
+    with open(name, "w") as f:
+        f.write("kernel,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean,hbm_bytes_per_launch(2*FETCH+WRITE)*1024\n")
+        for k, v in rows.items():
+            fe, wr = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+            f.write(f"\"{k}\",{fe:.1f},{wr:.1f},{(2*fe+wr)*1024:.0f}\n")
+            for sub, slot in SLOT.items():
+                if sub in k and "bf16x3" not in k:
+                    captures.append({"kernel": slot, "kernel_name": k, "frames_per_launch": fpl, "n_bins": n_bins,
+                                     "hbm_bytes_per_launch": round((2 * fe + wr) * 1024), "srchash": srchash,
+                                     "file": f"profiles/{tag}_pmc_traffic{'' if cfg == 1 else '_config2'}.csv"})
+    print(open(name).read())
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB per launch, mean); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
+                   "on gfx950 FETCH_SIZE reports half the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM); srchash = sha256 of the "
+                   "kernel sources the measured library was built from (pitchvis_amd/lib/libpvq.so.srchash)",
+           "captures": captures}, open("gpurun_out/traffic_latest.json", "w"), indent=1)
 st = glob.glob(f"gpurun_out/{tag}_stats/*/*kernel_stats.csv")[0]
 with open(f"gpurun_out/{tag}_kernel_stats.csv", "w") as f:
     for i, line in enumerate(open(st)):
         if i == 0 or "pvq::" in line:
             f.write(line)
-print(open(f"gpurun_out/{tag}_pmc_traffic.csv").read())
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"gpurun_out/{tag}_sq*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "pvq::" in r["Kernel_Name"] and "bf16x3" not in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(f"gpurun_out/{tag}_sq_counters.txt", "w") as out:
+    out.write(f"# rocprofv3 --pmc, mean per launch, bench.py configs[1]; kernel sources {srchash[:12]}\n")
+    for k, d in acc.items():
+        out.write(k + "\n")
+        for c, v in sorted(d.items()):
+            out.write(f"    {c:28s} {sum(v)/len(v):16.0f}  (n={len(v)})\n")
 print(open(f"gpurun_out/{tag}_kernel_stats.csv").read())
+print(open(f"gpurun_out/{tag}_sq_counters.txt").read())
 print(open(f"gpurun_out/{tag}_bench.json").read())
 PY

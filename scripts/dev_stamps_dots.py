@@ -6,7 +6,8 @@ out = os.path.join(ROOT, "gpurun_out", "stamps_dots.bin")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["PVQ_STAMPS_DOTS"] = out
 import numpy as np, torch
-import __graft_entry__ as g; g.build()
+import __graft_entry__ as g
+if not os.environ.get("PVQ_SKIP_BUILD"): g.build()
 import pitchvis_amd as P
 pp = P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 7, 36))
 v = P.Vqt(pp, 0); v.set_algo(2)

@@ -285,14 +285,21 @@ def test_config3_full_size_shard_on_one_gpu():
     shard edges; determinism; finite, 0..60 dB) plus oracle spot frames at the edges and inside."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from pitchvis_amd.sharding import global_stream, local_pcm
+    from pitchvis_amd.sharding import stream_slice
     pp, op = get_geom("bench_48k_288")
     v = P.Vqt.new(pp, 0)
     hop, F, world, rank = 256, 131072, 8, 3
-    stream = global_stream(0x5EED0003, world * F * hop, "cuda")
     s = plan_shard(world * F, hop, v.window_union, rank, world)
     assert s.n_frames == F and s.n_lead == v.window_union - hop == 16128
-    d_pcm = local_pcm(stream, s)
+    # the stream around this shard (the whole 1 GiB stream is never needed: it is a function of the sample index)
+    s_lo, s_hi = s.sample_begin - 2048 * hop - 40000, s.sample_end + 2048 * hop
+    around = stream_slice(0x5EED0003, s_lo, s_hi, "cuda")
+
+    class _Stream:   # global sample indices into the piece that was generated
+        def __getitem__(self, sl):
+            return around[sl.start - s_lo:sl.stop - s_lo]
+    stream = _Stream()
+    d_pcm = stream[s.sample_begin:s.sample_end].clone()
     words = (v.n_bins + 31) // 32
 
     def run(pcm, nf, n_lead):

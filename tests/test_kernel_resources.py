@@ -110,5 +110,5 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
             assert n >= 8, (name, waits[0])
             hits += 1
         assert hits >= 4, hits
-    for u in find("blockdft_banddots8_dbILi8ELi4ELi260"):
+    for u in find("blockdft_banddots4c_dbILi8ELi4ELi260ELi2"):
         assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # 8 waves x 2 workgroups per CU
