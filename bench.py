@@ -109,7 +109,22 @@ def cpu_baseline():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 256))   # every core this process may run on
+    # every core this process may actually run on: the affinity mask, capped by the cgroup's CPU quota where there is one (a GPU
+    # box of this pool shows 256 cores in the mask and grants 16)
+    quota = None
+    try:
+        q, per_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per_))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(round(q / per_)))
+        except Exception:
+            quota = None
+    cores = max(1, min(avail, quota or avail, 256))
     per = 2048
     t1, _ = _cpu_worker((1000, per, None))   # single thread first
     ms_default = _cpu_default_geometry_ms()
@@ -128,6 +143,7 @@ def cpu_baseline():
         "unit": "frames/s",
         "cores": cores,
         "cores_available": avail,
+        "cpu_quota": quota,
         "kind": "port",
         "sample": f"{cores} workers (every available core) x {per} frames (hop 256, 48 kHz/252 bins, white noise), VQT+dB+peaks, "
                   f"oracle/pvq_oracle.c -O2 (the reference's release profile); 1 core: {per / t1:.0f} frames/s",
@@ -135,10 +151,10 @@ def cpu_baseline():
         "value_native_O3": round(v_native, 1) if v_native else None,
         "default_geometry_ms_per_frame_1core": round(ms_default, 4),
         "reference_published_ms_per_frame": 0.091,
-        "note": "a floor for the reference's CPU path, not the reference: the port's scalar radix-2 real FFT (two stages per pass) is "
-                f"slower than rustfft's SIMD kernels — {ms_default:.3f} ms per frame here against the 0.091 ms VQT_REVIEW.md:363-365 "
-                "publishes at the same (default 22 050 Hz / 588-bin) geometry on an unspecified desktop CPU; value_native_O3: the same "
-                "source at -O3 -march=native on every core",
+        "note": "the port, not the reference's binary (Rust, cannot be built here): scalar radix-2 real FFT, two stages per pass, where the "
+                f"reference uses rustfft's SIMD kernels; {ms_default:.3f} ms per frame on one core of THIS host at the reference's default "
+                "22 050 Hz / 588-bin geometry against the 0.091 ms VQT_REVIEW.md:363-365 publishes for the crate on an unspecified desktop "
+                "CPU; value_native_O3: the same source at -O3 -march=native on the same cores; cores = min(affinity mask, cgroup CPU quota)",
     }
 
 

@@ -141,7 +141,10 @@ pvq_status pvq_vqt_calculate_batch_db_device(pvq_vqt *v, const float *d_pcm, siz
  * raises a sticky flag on the device while the frame's dB values are computed; the frames it touches are unspecified.
  * The synchronous host-buffer entry points (pvq_vqt_calculate_instant_db, pvq_vqt_calculate_batch_db, pvq_train_frames_db)
  * check the flag themselves and return PVQ_ERR_NONFINITE_INPUT.  For the asynchronous device-pointer entry points call
- * this: it waits for `stream`, returns PVQ_ERR_NONFINITE_INPUT if the flag is up (PVQ_OK otherwise) and clears it.
+ * this: it waits for `stream`, returns PVQ_ERR_NONFINITE_INPUT if the flag is up (PVQ_OK otherwise) and clears it (read and
+ * clear are one stream-ordered step on `stream`: poll on the stream the work was queued on).  The flag is per handle: a
+ * synchronous entry point reports its own input only — it clears, unreported, whatever an earlier asynchronous call of the
+ * same handle raised and nobody polled.
  */
 pvq_status pvq_vqt_input_status(pvq_vqt *v, void *stream);
 

@@ -942,6 +942,10 @@ pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, 
         return PVQ_ERR_INVALID_ARG;
     }
     PVQ_HIP(hipSetDevice(device_id_));
+    // a synchronous call answers for its own input only: whatever an earlier asynchronous call left in the flag (and nobody
+    // polled with input_status) is dropped here, not reported against this call's clean samples
+    PVQ_HIP(hipDeviceSynchronize());
+    PVQ_HIP(hipMemset(dev_->d_status, 0, sizeof(uint32_t)));
     const size_t n_samples = n_lead + n_frames * hop;
     pvq_status st = ensure_workspace(&ws_pcm_, &ws_pcm_cap_, n_samples * sizeof(float));
     if (st != PVQ_OK) return st;
@@ -996,11 +1000,13 @@ pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, 
 pvq_status Vqt::input_status(hipStream_t stream) {
     if (!has_device() || !dev_ || !dev_->d_status) return PVQ_OK;
     PVQ_HIP(hipSetDevice(device_id_));
-    PVQ_HIP(hipStreamSynchronize(stream));
+    // read and clear as ONE stream-ordered step behind everything the stream holds: a flag raised by work queued on this stream
+    // before the call is seen, nothing of it can fall between the read and the clear
     uint32_t flag = 0;
-    PVQ_HIP(hipMemcpy(&flag, dev_->d_status, sizeof flag, hipMemcpyDeviceToHost));
+    PVQ_HIP(hipMemcpyAsync(&flag, dev_->d_status, sizeof flag, hipMemcpyDeviceToHost, stream));
+    PVQ_HIP(hipMemsetAsync(dev_->d_status, 0, sizeof flag, stream));
+    PVQ_HIP(hipStreamSynchronize(stream));
     if (flag == 0) return PVQ_OK;
-    PVQ_HIP(hipMemset(dev_->d_status, 0, sizeof flag));
     set_last_error("non-finite sample (NaN / Inf) in the input: the affected frames are unspecified (the reference's audio "
                    "callback drops such chunks, audio_desktop.rs:102-105; peak_detection.rs:145 would panic)");
     return PVQ_ERR_NONFINITE_INPUT;

@@ -69,3 +69,19 @@ def test_instant_call_reports_it_too():
     with pytest.raises(P.PvqError) as e:
         v.calculate_vqt_instant_in_db(x)
     assert e.value.status == _lib.PVQ_ERR_NONFINITE_INPUT
+
+
+def test_a_synchronous_call_answers_for_its_own_input_only():
+    """The flag is per handle: an asynchronous call that raised it and was never polled must not make the next synchronous
+    call fail on clean samples (include/pvq.h: the synchronous entry points clear what they did not raise)."""
+    pp, _ = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    hop, nf = 256, 200
+    clean = white_noise(hop * nf, 15)
+    dirty = clean.copy()
+    dirty[hop * 50] = np.nan
+    d_db = torch.empty((nf, v.n_bins), device="cuda")
+    v.calculate_batch_db_device(torch.from_numpy(dirty).cuda(), hop, nf, d_db)   # raises the flag, nobody polls
+    ref = v.calculate_batch_db(clean, hop, nf)                                    # clean input: PVQ_OK
+    assert np.isfinite(ref).all()
+    v.input_status()                                                               # and nothing is left behind
