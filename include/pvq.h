@@ -294,6 +294,40 @@ uint32_t pvq_analysis_state_get_peaks_continuous(const pvq_analysis_state *s, fl
 float pvq_analysis_state_scene_calmness(const pvq_analysis_state *s);            /* smoothed_scene_calmness.get() */
 float pvq_analysis_state_tuning_grid_inaccuracy(const pvq_analysis_state *s);    /* smoothed_tuning_grid_inaccuracy.get() */
 
+/* ---- AnalysisState for MANY streams, on the GPU ------------------------------------------------------
+ * preprocess() cannot be split over time, but streams are independent (the trainer analyses many files side by side,
+ * pitchvis_train/src/train.rs:146-155): one wavefront owns one stream and walks its frames in order, thousands of streams in
+ * parallel ("replicas only": no exchange between streams or devices).  Same arithmetic, same operation order as the host
+ * pvq_analysis_state above; every stream starts as AnalysisState::new leaves it (analysis.rs:192-241) and keeps its state
+ * between calls. */
+typedef struct pvq_analysis_batch pvq_analysis_batch;
+/* per-frame results, DEVICE pointers, any may be NULL (center and size go together, with max_peaks > 0).  Per-bin fields:
+ * [n_streams][n_frames][n_bins]; peak_mask [..][..][ceil(n_bins/32)]; center / size [..][..][max_peaks] (ascending center, entries
+ * beyond the frame's count untouched); peak_count, scene_calmness, tuning_grid_inaccuracy [n_streams][n_frames]. */
+typedef struct pvq_analysis_batch_outputs {
+    float *x_vqt_smoothed, *x_vqt_peakfiltered, *x_vqt_afterglow, *calmness, *pitch_accuracy, *pitch_deviation;
+    uint32_t *peak_mask, *peak_count;
+    float *center, *size;
+    uint32_t max_peaks;
+    float *scene_calmness, *tuning_grid_inaccuracy;
+} pvq_analysis_batch_outputs;
+/* n_streams AnalysisState::new(range, params) on device `device_id` (params NULL: AnalysisParameters::default) */
+pvq_status pvq_analysis_batch_create(int device_id, float min_freq, uint32_t octaves, uint32_t buckets_per_octave,
+                                     const pvq_analysis_full_params *params, uint32_t n_streams, pvq_analysis_batch **out);
+void pvq_analysis_batch_destroy(pvq_analysis_batch *b);
+/* AnalysisState::update_vqt_smoothing_duration (analysis.rs:251) on every stream */
+pvq_status pvq_analysis_batch_update_vqt_smoothing_duration(pvq_analysis_batch *b, int has_duration, uint64_t duration_ns);
+/* AnalysisState::preprocess (analysis.rs:288) for n_frames frames of every stream, in order: d_db [n_streams][n_frames][n_bins]
+ * (device).  frame_time_ns applies to every frame unless frame_times_ns (HOST array of n_frames) is given.  Asynchronous on
+ * `stream`. */
+pvq_status pvq_analysis_batch_preprocess_device(pvq_analysis_batch *b, const float *d_db, size_t n_frames, uint64_t frame_time_ns,
+                                                const uint64_t *frame_times_ns, const pvq_analysis_batch_outputs *outs,
+                                                void *stream);
+/* the state of one stream after the last call (synchronises): a pub field as pvq_analysis_state_get_field, and the two scalars */
+pvq_status pvq_analysis_batch_get_field(pvq_analysis_batch *b, uint32_t stream_index, pvq_analysis_field f, float *out);
+pvq_status pvq_analysis_batch_get_scalars(pvq_analysis_batch *b, uint32_t stream_index, float *scene_calmness,
+                                          float *tuning_grid_inaccuracy);
+
 /* ------------------------------------------------------------------------------------------------
  * Callers either side of the path: host code around the GPU frames.
  * ---------------------------------------------------------------------------------------------- */

@@ -24,7 +24,7 @@ from ._lib import ALGO_AUTO, ALGO_BLOCKDFT, ALGO_FFT, GEMM_BF16X3, GEMM_F32  # n
 __all__ = [
     "VqtRange", "VqtParameters", "VqtError", "AboveNyquist", "WindowExceedsNFft", "PvqError", "WindowGroup",
     "VqtKernel", "Vqt", "PeakDetectionParameters", "AnalysisParameters", "ContinuousPeak", "FrameAnalysis",
-    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT", "GEMM_F32", "GEMM_BF16X3", "AnalysisState", "FullAnalysisParameters",
+    "ALGO_AUTO", "ALGO_FFT", "ALGO_BLOCKDFT", "GEMM_F32", "GEMM_BF16X3", "AnalysisState", "AnalysisBatch", "FullAnalysisParameters",
 ]
 
 
@@ -453,6 +453,61 @@ class FullAnalysisParameters:
             ns(self.vqt_smoothing_duration_base), self.vqt_smoothing_calmness_min, self.vqt_smoothing_calmness_max,
             ns(self.note_calmness_smoothing_duration), ns(self.scene_calmness_smoothing_duration),
             ns(self.tuning_inaccuracy_smoothing_duration), self.harmonic_threshold)
+
+
+class AnalysisBatch:
+    """AnalysisState::preprocess for MANY streams on the GPU (pvq_analysis_batch_*): one wavefront per stream walks its frames in
+    order, streams in parallel; same arithmetic and operation order as the host AnalysisState, state kept between calls."""
+
+    _FIELDS = {"x_vqt_smoothed": 0, "x_vqt_peakfiltered": 1, "x_vqt_afterglow": 2, "calmness": 3, "pitch_accuracy": 4, "pitch_deviation": 5}
+
+    def __init__(self, range: VqtRange, n_streams: int, params: Optional["FullAnalysisParameters"] = None, device: int = 0):
+        self._L = _lib.load()
+        self.range, self.n_streams = range, n_streams
+        self.params = params or FullAnalysisParameters()
+        self.n_bins = range.octaves * range.buckets_per_octave
+        self._h = C.c_void_p()
+        cp = self.params._c()
+        _check(self._L.pvq_analysis_batch_create(device, range.min_freq, range.octaves, range.buckets_per_octave, C.byref(cp), n_streams,
+                                                 C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._L.pvq_analysis_batch_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def update_vqt_smoothing_duration(self, new_duration: Optional[float]) -> None:
+        if new_duration is None:
+            _check(self._L.pvq_analysis_batch_update_vqt_smoothing_duration(self._h, 0, 0))
+        else:
+            _check(self._L.pvq_analysis_batch_update_vqt_smoothing_duration(self._h, 1, int(round(new_duration * 1e9))))
+
+    def preprocess_device(self, d_db, n_frames: int, frame_time: float, outputs: Optional[dict] = None, max_peaks: int = 0,
+                          frame_times=None, stream=None) -> None:
+        """d_db: device tensor [n_streams][n_frames][n_bins]; outputs: {field name: device tensor} (see pvq_analysis_batch_outputs);
+        frame_time in seconds, or frame_times: per-frame seconds (host sequence of n_frames).  Asynchronous."""
+        o = _lib.CAnalysisBatchOutputs()
+        for k, t in (outputs or {}).items():
+            setattr(o, k, _ptr(t))
+        o.max_peaks = max_peaks
+        ft = None
+        if frame_times is not None:
+            ft = (C.c_uint64 * n_frames)(*[int(round(x * 1e9)) for x in frame_times])
+        _check(self._L.pvq_analysis_batch_preprocess_device(self._h, _ptr(d_db), n_frames, int(round(frame_time * 1e9)), ft, C.byref(o),
+                                                            _stream_handle(stream)))
+
+    def field(self, stream_index: int, name: str) -> np.ndarray:
+        out = np.empty(self.n_bins, np.float32)
+        _check(self._L.pvq_analysis_batch_get_field(self._h, stream_index, AnalysisBatch._FIELDS[name], out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def scalars(self, stream_index: int):
+        a, b = C.c_float(), C.c_float()
+        _check(self._L.pvq_analysis_batch_get_scalars(self._h, stream_index, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
 
 
 class AnalysisState:

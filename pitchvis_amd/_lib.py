@@ -20,6 +20,8 @@ EXPORTS = [
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_plan_shard", "pvq_vqt_analyze_batch_multi", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
     "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_set_workspace_limit", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
+    "pvq_analysis_batch_create", "pvq_analysis_batch_destroy", "pvq_analysis_batch_update_vqt_smoothing_duration",
+    "pvq_analysis_batch_preprocess_device", "pvq_analysis_batch_get_field", "pvq_analysis_batch_get_scalars",
     "pvq_analysis_state_update_vqt_smoothing_duration", "pvq_analysis_state_preprocess",
     "pvq_analysis_state_bin_to_frequency", "pvq_analysis_state_n_buckets", "pvq_analysis_state_get_field",
     "pvq_analysis_state_get_peaks", "pvq_analysis_state_get_peaks_continuous", "pvq_analysis_state_scene_calmness",
@@ -70,6 +72,12 @@ class CAnalysisParams(C.Structure):
         ("highest_bassnote", C.c_uint32),
         ("harmonic_threshold", C.c_float),
     ]
+
+
+class CAnalysisBatchOutputs(C.Structure):   # pvq_analysis_batch_outputs (device pointers)
+    _fields_ = [(n, C.c_void_p) for n in ("x_vqt_smoothed", "x_vqt_peakfiltered", "x_vqt_afterglow", "calmness", "pitch_accuracy",
+                                          "pitch_deviation", "peak_mask", "peak_count", "center", "size")] + \
+               [("max_peaks", C.c_uint32), ("scene_calmness", C.c_void_p), ("tuning_grid_inaccuracy", C.c_void_p)]
 
 
 class CShard(C.Structure):   # pvq_shard
@@ -164,6 +172,13 @@ def load():
     L.pvq_analysis_full_default_params.argtypes = [afp]
     L.pvq_analysis_state_create.argtypes = [C.c_float, C.c_uint32, C.c_uint32, afp, C.POINTER(vp)]
     L.pvq_analysis_state_create.restype = C.c_int
+    L.pvq_analysis_batch_create.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_uint32, afp, C.c_uint32, C.POINTER(vp)]; L.pvq_analysis_batch_create.restype = C.c_int
+    L.pvq_analysis_batch_destroy.argtypes = [vp]
+    L.pvq_analysis_batch_update_vqt_smoothing_duration.argtypes = [vp, C.c_int, C.c_uint64]; L.pvq_analysis_batch_update_vqt_smoothing_duration.restype = C.c_int
+    L.pvq_analysis_batch_preprocess_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(CAnalysisBatchOutputs), vp]
+    L.pvq_analysis_batch_preprocess_device.restype = C.c_int
+    L.pvq_analysis_batch_get_field.argtypes = [vp, C.c_uint32, C.c_int, fp]; L.pvq_analysis_batch_get_field.restype = C.c_int
+    L.pvq_analysis_batch_get_scalars.argtypes = [vp, C.c_uint32, fp, fp]; L.pvq_analysis_batch_get_scalars.restype = C.c_int
     L.pvq_analysis_state_destroy.argtypes = [vp]
     L.pvq_analysis_state_update_vqt_smoothing_duration.argtypes = [vp, C.c_int, C.c_uint64]
     L.pvq_analysis_state_update_vqt_smoothing_duration.restype = C.c_int

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "analysis_batch.hpp"
 #include "analysis_host.hpp"
 #include "consumers_host.hpp"
 #include "multi_host.hpp"
@@ -20,6 +21,9 @@ struct pvq_vqt {
 };
 struct pvq_analysis_state {
     std::unique_ptr<pvq::AnalysisState> impl;
+};
+struct pvq_analysis_batch {
+    std::unique_ptr<pvq::AnalysisBatch> impl;
 };
 struct pvq_mono_agc {
     pvq::MonoAgc impl;
@@ -454,6 +458,24 @@ void pvq_analysis_full_default_params(pvq_analysis_full_params* p) {
     } catch (...) { (void)translate_exception(); }
 }
 
+static pvq::FullAnalysisParameters full_to_cpp(const pvq_analysis_full_params* params) {
+    pvq::FullAnalysisParameters q;
+    if (params) {
+        q.spectrogram_length = params->spectrogram_length;
+        q.peak_config = {params->peak_min_prominence, params->peak_min_height};
+        q.bassline_peak_config = {params->bass_min_prominence, params->bass_min_height};
+        q.highest_bassnote = params->highest_bassnote;
+        q.vqt_smoothing_duration_base = pvq::Duration{params->vqt_smoothing_duration_base_ns};
+        q.vqt_smoothing_calmness_min = params->vqt_smoothing_calmness_min;
+        q.vqt_smoothing_calmness_max = params->vqt_smoothing_calmness_max;
+        q.note_calmness_smoothing_duration = pvq::Duration{params->note_calmness_smoothing_duration_ns};
+        q.scene_calmness_smoothing_duration = pvq::Duration{params->scene_calmness_smoothing_duration_ns};
+        q.tuning_inaccuracy_smoothing_duration = pvq::Duration{params->tuning_inaccuracy_smoothing_duration_ns};
+        q.harmonic_threshold = params->harmonic_threshold;
+    }
+    return q;
+}
+
 pvq_status pvq_analysis_state_create(float min_freq, uint32_t octaves, uint32_t buckets_per_octave,
                                      const pvq_analysis_full_params* params, pvq_analysis_state** out) {
     try {
@@ -463,20 +485,7 @@ pvq_status pvq_analysis_state_create(float min_freq, uint32_t octaves, uint32_t 
             pvq::set_last_error("invalid VqtRange");
             return PVQ_ERR_INVALID_ARG;
         }
-        pvq::FullAnalysisParameters q;
-        if (params) {
-            q.spectrogram_length = params->spectrogram_length;
-            q.peak_config = {params->peak_min_prominence, params->peak_min_height};
-            q.bassline_peak_config = {params->bass_min_prominence, params->bass_min_height};
-            q.highest_bassnote = params->highest_bassnote;
-            q.vqt_smoothing_duration_base = pvq::Duration{params->vqt_smoothing_duration_base_ns};
-            q.vqt_smoothing_calmness_min = params->vqt_smoothing_calmness_min;
-            q.vqt_smoothing_calmness_max = params->vqt_smoothing_calmness_max;
-            q.note_calmness_smoothing_duration = pvq::Duration{params->note_calmness_smoothing_duration_ns};
-            q.scene_calmness_smoothing_duration = pvq::Duration{params->scene_calmness_smoothing_duration_ns};
-            q.tuning_inaccuracy_smoothing_duration = pvq::Duration{params->tuning_inaccuracy_smoothing_duration_ns};
-            q.harmonic_threshold = params->harmonic_threshold;
-        }
+        const pvq::FullAnalysisParameters q = full_to_cpp(params);
         pvq::VqtRange r;
         r.min_freq = min_freq;
         r.octaves = octaves;
@@ -572,6 +581,61 @@ float pvq_analysis_state_tuning_grid_inaccuracy(const pvq_analysis_state* s) {
     try {
         return s ? s->impl->smoothed_tuning_grid_inaccuracy.get() : 0.0f;
     } catch (...) { (void)translate_exception(); return 0.0f; }
+}
+
+pvq_status pvq_analysis_batch_create(int device_id, float min_freq, uint32_t octaves, uint32_t buckets_per_octave,
+                                     const pvq_analysis_full_params* params, uint32_t n_streams, pvq_analysis_batch** out) {
+    try {
+        if (!out) return null_handle();
+        *out = nullptr;
+        pvq::VqtRange r;
+        r.min_freq = min_freq;
+        r.octaves = octaves;
+        r.buckets_per_octave = buckets_per_octave;
+        std::unique_ptr<pvq::AnalysisBatch> impl;
+        const pvq_status st = pvq::AnalysisBatch::create(device_id, r, full_to_cpp(params), n_streams, impl);
+        if (st != PVQ_OK) return st;
+        *out = new pvq_analysis_batch{std::move(impl)};
+        return PVQ_OK;
+    } catch (...) { return translate_exception(); }
+}
+void pvq_analysis_batch_destroy(pvq_analysis_batch* b) {
+    try {
+        delete b;
+    } catch (...) { (void)translate_exception(); }
+}
+pvq_status pvq_analysis_batch_update_vqt_smoothing_duration(pvq_analysis_batch* b, int has_duration, uint64_t duration_ns) {
+    try {
+        if (!b) return null_handle();
+        b->impl->update_vqt_smoothing_duration(has_duration != 0, pvq::Duration{duration_ns});
+        return PVQ_OK;
+    } catch (...) { return translate_exception(); }
+}
+pvq_status pvq_analysis_batch_preprocess_device(pvq_analysis_batch* b, const float* d_db, size_t n_frames, uint64_t frame_time_ns,
+                                                const uint64_t* frame_times_ns, const pvq_analysis_batch_outputs* outs, void* stream) {
+    try {
+        if (!b) return null_handle();
+        pvq::AnalysisBatchOutputs o;
+        if (outs) {
+            o.x_vqt_smoothed = outs->x_vqt_smoothed; o.x_vqt_peakfiltered = outs->x_vqt_peakfiltered; o.x_vqt_afterglow = outs->x_vqt_afterglow;
+            o.calmness = outs->calmness; o.pitch_accuracy = outs->pitch_accuracy; o.pitch_deviation = outs->pitch_deviation;
+            o.peak_mask = outs->peak_mask; o.peak_count = outs->peak_count; o.center = outs->center; o.size = outs->size;
+            o.max_peaks = outs->max_peaks; o.scene_calmness = outs->scene_calmness; o.tuning_grid_inaccuracy = outs->tuning_grid_inaccuracy;
+        }
+        return b->impl->preprocess_device(d_db, n_frames, pvq::Duration{frame_time_ns}, frame_times_ns, o, static_cast<hipStream_t>(stream));
+    } catch (...) { return translate_exception(); }
+}
+pvq_status pvq_analysis_batch_get_field(pvq_analysis_batch* b, uint32_t stream_index, pvq_analysis_field f, float* out) {
+    try {
+        if (!b) return null_handle();
+        return b->impl->get_field(stream_index, (int)f, out);
+    } catch (...) { return translate_exception(); }
+}
+pvq_status pvq_analysis_batch_get_scalars(pvq_analysis_batch* b, uint32_t stream_index, float* scene_calmness, float* tuning_grid_inaccuracy) {
+    try {
+        if (!b) return null_handle();
+        return b->impl->get_scalars(stream_index, scene_calmness, tuning_grid_inaccuracy);
+    } catch (...) { return translate_exception(); }
 }
 
 pvq_status pvq_vqt_set_profiling(pvq_vqt* v, int enable) {

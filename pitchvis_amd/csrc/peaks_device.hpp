@@ -253,7 +253,7 @@ __device__ __forceinline__ void pk_distance_rounds(const float* x, int n, int di
 // scratch: peaks_scratch_bytes() bytes of LDS private to this wave.  Called by all 64 lanes.
 template <int NK>
 __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scratch, size_t frame, const PeakParamsDev& a,
-                                              int lane) {
+                                              int lane, uint32_t* total_out = nullptr) {   // total_out: the frame's number of peaks (their bins, ascending, are left in scratch + npad as u16)
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
     const int words = (n + 31) / 32;
@@ -338,6 +338,7 @@ __device__ __forceinline__ void peaks_wave_nk(const float* x, unsigned char* scr
         if (is_peak) plist[slot] = (uint16_t)i;
     }
     if (a.count && lane == 0) a.count[frame] = total;
+    if (total_out) *total_out = total;
     if (a.center) {
         // refine all peaks of the frame side by side: one lane per peak
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
