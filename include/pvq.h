@@ -398,7 +398,9 @@ void pvq_host_free(void *p);
 
 /* timing hook for bench.py: elapsed GPU milliseconds of the dominant kernel launches of the
  * last batch call, measured with HIP events on the stream the kernels were launched on.
- * Enable with pvq_vqt_set_profiling(v, 1) (resets the statistics); reading synchronises. */
+ * Enable with pvq_vqt_set_profiling(v, 1) (resets the statistics); reading synchronises.  enable == 2 times only the transform's
+ * main kernel (the fused GEMM + tree, or the FFT-path kernel): two event records per step instead of eight — the events themselves
+ * cost ~3 us each on the stream. */
 pvq_status pvq_vqt_set_profiling(pvq_vqt *v, int enable);
 /* out_ms[i] for kernel slot i (see pvq_vqt_kernel_name); returns the number of slots filled */
 uint32_t pvq_vqt_last_kernel_ms(pvq_vqt *v, float *out_ms, uint32_t capacity);

@@ -398,8 +398,9 @@ class Vqt:
     def last_algo(self) -> int:
         return self._L.pvq_vqt_last_algo(self._h)
 
-    def set_profiling(self, on: bool) -> None:
-        _check(self._L.pvq_vqt_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on) -> None:
+        """False / True: HIP events around every kernel launch; 2: only around the transform's main kernel"""
+        _check(self._L.pvq_vqt_set_profiling(self._h, 2 if on == 2 else (1 if on else 0)))
 
     def last_kernel_ms(self) -> dict:
         """mean GPU ms per launch of each kernel since set_profiling(True)"""

@@ -641,7 +641,7 @@ pvq_status pvq_analysis_batch_get_scalars(pvq_analysis_batch* b, uint32_t stream
 pvq_status pvq_vqt_set_profiling(pvq_vqt* v, int enable) {
     try {
         if (!v) return null_handle();
-        v->impl->set_profiling(enable != 0);
+        v->impl->set_profiling(enable == 2 ? 2 : (enable != 0 ? 1 : 0));
         return PVQ_OK;
     } catch (...) { return translate_exception(); }
 }

@@ -751,12 +751,14 @@ pvq_status Vqt::ensure_workspace(void** ptr, size_t* cap, size_t bytes) {
     return PVQ_OK;
 }
 
-void Vqt::set_profiling(bool on) {
-    profiling_ = on;
+void Vqt::set_profiling(int mode) {
+    profiling_ = mode != 0;
+    profiling_main_only_ = mode == 2;
     for (int s = 0; s < N_SLOTS; ++s) ev_count_[s] = 0;
 }
 
 void Vqt::slot_begin(int slot, hipStream_t s) {
+    if (profiling_main_only_ && slot != SLOT_BLOCKDFT_GEMM && slot != SLOT_FFT_FRAMES) return;
     if (!profiling_ || ev_count_[slot] >= kMaxTimedLaunches) return;
     const int i = ev_count_[slot];
     if ((int)ev_[slot][0].size() <= i) {
@@ -769,6 +771,7 @@ void Vqt::slot_begin(int slot, hipStream_t s) {
     (void)hipEventRecord(ev_[slot][0][i], s);
 }
 void Vqt::slot_end(int slot, hipStream_t s) {
+    if (profiling_main_only_ && slot != SLOT_BLOCKDFT_GEMM && slot != SLOT_FFT_FRAMES) return;
     if (!profiling_ || ev_count_[slot] >= kMaxTimedLaunches) return;
     (void)hipEventRecord(ev_[slot][1][ev_count_[slot]], s);
     ++ev_count_[slot];

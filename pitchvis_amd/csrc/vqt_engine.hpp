@@ -88,7 +88,7 @@ class Vqt {
     pvq_algo last_algo() const { return last_algo_; }
     // HIP-event timing of every kernel launch (per slot) on the stream it is launched on.
     // Enabling resets the statistics; last_kernel_ms reports the mean per launch since then.
-    void set_profiling(bool on);
+    void set_profiling(int mode);   // 0 off; 1 HIP events around every kernel launch; 2 only around the transform's main kernel (two events per step instead of eight)
     uint32_t last_kernel_ms(float* out, uint32_t cap);
     uint32_t last_kernel_launches(uint32_t* out, uint32_t cap) const;
     uint32_t last_frames_per_launch() const { return last_frames_per_launch_; }
@@ -129,7 +129,7 @@ class Vqt {
     DeviceTables* dev_ = nullptr;
     pvq_algo algo_ = PVQ_ALGO_AUTO;
     pvq_algo last_algo_ = PVQ_ALGO_AUTO;
-    bool profiling_ = false;
+    bool profiling_ = false, profiling_main_only_ = false;
     // host-buffer batches: upload / run / download streams and their events
     bool host_streams_ready_ = false;
     hipStream_t host_streams_[3] = {nullptr, nullptr, nullptr};
