@@ -3,7 +3,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
-import __graft_entry__ as g; g.build()
+import __graft_entry__ as g
+if not os.environ.get("PVQ_SKIP_BUILD"): g.build()
 import pitchvis_amd as P
 from helpers import GEOMS, get_geom
 for name in GEOMS:

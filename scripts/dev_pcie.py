@@ -2,7 +2,8 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import __graft_entry__ as g; g.build()
+import __graft_entry__ as g
+if not os.environ.get("PVQ_SKIP_BUILD"): g.build()
 import pitchvis_amd as P
 pp = P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 7, 36))
 v = P.Vqt(pp, 0)

@@ -3,7 +3,8 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-import __graft_entry__ as g; g.build()
+import __graft_entry__ as g
+if not os.environ.get("PVQ_SKIP_BUILD"): g.build()
 import pitchvis_amd as P
 from helpers import GEOMS, get_geom
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
