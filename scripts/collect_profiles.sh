@@ -9,8 +9,6 @@ TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python3 $ROOT/bench.py --steps 10 --warmup 3 --config 2 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2>> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 # (the program goes directly after `--`: no env / bash -c hop under rocprofv3)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
@@ -80,5 +78,9 @@ with open(f"gpurun_out/{tag}_sq_counters.txt", "w") as out:
             out.write(f"    {c:28s} {sum(v)/len(v):16.0f}  (n={len(v)})\n")
 print(open(f"gpurun_out/{tag}_kernel_stats.csv").read())
 print(open(f"gpurun_out/{tag}_sq_counters.txt").read())
-print(open(f"gpurun_out/{tag}_bench.json").read())
 PY
+# the bench lines LAST: they attach the traffic capture just taken on this build (profiles/traffic_latest.json on this box)
+cp $OUT/traffic_latest.json $ROOT/profiles/traffic_latest.json
+python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 $ROOT/bench.py --steps 10 --warmup 3 --config 2 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2>> $OUT/${TAG}_bench.err
+cat $OUT/${TAG}_bench.json
