@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVQ_ABI_VERSION 2
+#define PVQ_ABI_VERSION 3   /* 3: + pvq_vqt_set_workspace_limit, pvq_plan_shard, pvq_vqt_analyze_batch_multi, pvq_analysis_batch_*, profiling mode 2; per-call NaN flag semantics of the synchronous entry points */
 
 /* replaces VqtParameters + VqtRange (vqt.rs:238-262, 278-331), flattened POD */
 typedef struct pvq_vqt_params {
