@@ -114,8 +114,9 @@ struct BlockDftTables {
     // frame-stripe tile order of the fused kernels, built per (frames, tile rows) and kept for the next launch
     struct TileList {
         int4* d = nullptr; size_t cap = 0;
-        int nf = -1, bm = 0, blocks = 0;
-    } tile_lists[2];   // two slots: the full sub-batch and a batch's shorter last one alternate without rebuilding
+        int nf = -1, bm = 0, wide = 0, blocks = 0;
+        long long base = 0; unsigned pcm_bytes = 0;   // where the stream starts and ends relative to the tiles: which tiles may pair up (wide entries)
+    } tile_lists[4];   // four slots: a batch's first, middle and last sub-batch alternate without rebuilding
     int tile_list_next = 0;
     unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch: 4 slots per sampled tile
     float4* d_E16 = nullptr;       // E in the B-operand order of the 16x16x4 GEMM: [column tile][k < hop / 2][n < 16]
@@ -237,7 +238,11 @@ __device__ __forceinline__ FusedTile fused_tile_of(const GemmTreeArgs& a, const 
     return t;
 }
 template <int BM = FT_BM>
-__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) { return fused_tile_of<BM>(a, a.tile_list[blockIdx.x]); }
+__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {   // (the kernels of 32-column tiles: their lists carry no wide entries)
+    int4 e = a.tile_list[blockIdx.x];
+    e.x &= 7;
+    return fused_tile_of<BM>(a, e);
+}
 
 // doubling tree over the [128][32 complex] P tile in LDS (rows padded to 33 so that the transposed store
 // below is bank-conflict free), then the store of the S complete frames, column-major
@@ -602,10 +607,10 @@ __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, fl
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
     const int K2 = a.K / 2;
-    long long jf0[2], jb0[2];
+    int jf0[2], jb0[2];   // sample indices relative to pcm_base (|.| < 2^30: the launch's stream is at most 4 GB)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
+        const int row_lo = (int)tile_lo + (wave * 32 + mt * 16 + m16) * a.K;
         jf0[mt] = row_lo + 8 * kq;
         jb0[mt] = row_lo + a.K - 4 - 8 * kq;
     }
@@ -616,9 +621,9 @@ __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, fl
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const long long xf = jf0[mt] + so + t, xb = jb0[mt] - so + t;
-                fr[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xf >= 0 ? (unsigned)(xf * 4ll) : 0xFFFFFFFCu, 0, 0));
-                bk[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xb >= 0 ? (unsigned)(xb * 4ll) : 0xFFFFFFFCu, 0, 0));
+                const int xf = jf0[mt] + so + t, xb = jb0[mt] - so + t;
+                fr[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xf >= 0 ? (unsigned)xf * 4u : 0xFFFFFFFCu, 0, 0));
+                bk[buf][mt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xb >= 0 ? (unsigned)xb * 4u : 0xFFFFFFFCu, 0, 0));
             }
     };
     float4* El = reinterpret_cast<float4*>(smem);   // [rows][16]
@@ -657,25 +662,134 @@ __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, fl
     }
 }
 
-template <int BM>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 complex columns
-__global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) {   // 4 waves per SIMD = two 512-thread (four 256-thread) workgroups per CU: at most 128 registers
-    constexpr int B_FLOATS = FR_KC * FT_BN;
-    constexpr int P_FLOATS = (BM + 15) * FT_LDP * 2;   // 15 spare rows: the register tree levels read their halo without a range check
-    __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice, then the P tile
-    __shared__ float2 tw_lds[FT_MAXL][CB_C];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FusedTile T = fused_tile<BM>(a);
-    const int f0 = T.f0, nt = T.nt;
-    if (f0 >= T.nfr) return;
-    const int stamp_slot = blockIdx.x;
-    PVQ_STAMP(0);
-    // the tile's combine twiddles (levels x 32 complex columns = 64 floats per level): wave l < levels copies level l, a dword per lane
+// WIDE tiles: the same rows against TWO neighbouring column tiles (64 complex columns) in one K loop.  What bounds a workgroup is
+// not a resource but the chain of latencies a tile pays once — launch gap, descriptor, the first operand burst, the waves' skew at
+// the loop's end — so a wide tile pays them once for twice the MFMAs.  A wave holds 16 accumulators (64 registers);
+// the A operands are single-buffered per 16-row tile and fetched one STAGE ahead — stage = (row tile, double k group) = 64 MFMAs,
+// the same prefetch distance in MFMAs as the narrow loop's double buffer: while row tile 1 of double group G runs, row tile 0's
+// loads of group G + 1 are in flight, and so on in turn.  Every accumulator adds the same products in the same order as in the
+// narrow loop: results are bit-identical whichever form a tile takes.  The two tiles' slices of E lie 32 KB apart in LDS.
+template <int BM>
+__device__ __forceinline__ void fused_f32_kloop64(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
+                                                  f32x4a (&accR)[2][4], f32x4a (&accI)[2][4], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
+    constexpr int THREADS = 2 * BM, NWV = THREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const int K2 = a.K / 2;
+    const int nG = K2 / 32;
+    unsigned vf[2], vb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
+        vf[mt] = (unsigned)((row_lo + 8 * kq) * 4ll);
+        vb[mt] = (unsigned)((row_lo + a.K - 8 - 8 * kq) * 4ll) - 128u * (unsigned)(nG - 1);
+    }
+    float fr[2][8], bk[2][8];
+    auto load_stage = [&](int mt, int G) {   // unconditional, clamped (see fused_f32_kloop16)
+        const int Gc = G < nG - 1 ? G : nG - 1;
+        const int sf = 128 * Gc, sb = 128 * (nG - 1 - Gc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)vf[mt], sf + 16 * h, 0);
+            const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)vb[mt], sb + 16 * h, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fr[mt][4 * h + t] = v[t];
+                bk[mt][4 * h + t] = w[t];
+            }
+        }
+    };
+    float4* El = reinterpret_cast<float4*>(smem);   // [column tile][FR_KC rows][16]
+    const float4* erow = El + (8 * kq) * 16 + m16;
+    auto b_at = [&](int Gl, int r, int ct) { return erow[(32 * Gl + r) * 16 + ct * (FR_KC * 16)]; };
+    // one stage: 8 k rows x 2 column tiles = 16 steps of 4 MFMAs, the B operand fetched one step ahead
+    auto mfma_stage = [&](int mt, int Gl, int Gl_next, float4 bc) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = i >> 1, ct = i & 1;
+            const float4 bn = i < 15 ? b_at(Gl, (i + 1) >> 1, (i + 1) & 1) : b_at(Gl_next, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const float sm = fr[mt][r] + bk[mt][7 - r];
+            const float df = fr[mt][r] - bk[mt][7 - r];
+            accR[mt][2 * ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, bc.x, accR[mt][2 * ct], 0, 0, 0);
+            accR[mt][2 * ct + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, bc.y, accR[mt][2 * ct + 1], 0, 0, 0);
+            accI[mt][2 * ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, bc.z, accI[mt][2 * ct], 0, 0, 0);
+            accI[mt][2 * ct + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, bc.w, accI[mt][2 * ct + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bc = bn;
+        }
+        return bc;
+    };
+    auto stage_e = [&](int kc, int rows) {   // both tiles' slices, 1 KB pieces dealt to the waves
+        constexpr int FULL = FR_KC / 4 / NWV;
+        if (rows == FR_KC && FR_KC / 4 % NWV == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < FULL; ++q)
+                    lds_dma16(e_tile + (size_t)ct * K2 * 16 + (size_t)kc * 16 + (q * NWV + wave) * 64 + lane, El + ct * (FR_KC * 16) + (q * NWV + wave) * 64);
+        } else {
+            for (int j = wave; j < 2 * (rows / 4); j += NWV) {
+                const int ct = j >= rows / 4, jj = ct ? j - rows / 4 : j;
+                lds_dma16(e_tile + (size_t)ct * K2 * 16 + (size_t)kc * 16 + jj * 64 + lane, El + ct * (FR_KC * 16) + jj * 64);
+            }
+        }
+    };
+    stage_e(0, K2 < FR_KC ? K2 : FR_KC);
+    // twiddles: levels x 64 complex columns = two 64-float pieces per level, [column tile][level][32]
+    for (int j = wave; j < 2 * tw_levels; j += NWV) {
+        const int l = j >> 1, ct = j & 1;
+        lds_dma4(tw_src + (size_t)l * tw_stride + ct * (2 * CB_C), tw_dst + (ct * FT_MAXL + l) * (2 * CB_C));
+    }
+    load_stage(0, 0);
+    load_stage(1, 0);
+    __syncthreads();
+    PVQ_STAMP(7);
+    for (int kc = 0; kc < K2; kc += FR_KC) {
+        const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
+        if (kc > 0) {
+            __syncthreads();
+            stage_e(kc, rows);
+            __syncthreads();
+        }
+        const int ng = rows / 32, G0 = kc / 32;
+        float4 bc = b_at(0, 0, 0);
+        for (int Gl = 0; Gl < ng; ++Gl) {
+            bc = mfma_stage(0, Gl, Gl, bc);
+            load_stage(0, G0 + Gl + 1);
+            bc = mfma_stage(1, Gl, Gl + 1, bc);
+            load_stage(1, G0 + Gl + 1);
+        }
+    }
+}
+
+// P' accumulators of one 32-column tile -> LDS as [row][32 complex + pad]  (C/D layout of the 16x16 MFMA: column = lane & 15,
+// rows 4 (lane >> 4) + r), and the 15 spare rows zeroed
+template <int BM, int NP, int NP0>
+__device__ __forceinline__ void fused_dump_p(float* smem, const f32x4a (&accR)[2][NP], const f32x4a (&accI)[2][NP], int tid) {
+    float2 (*Pt)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Pt[wave * 32 + mt * 16 + 4 * kq + r][np * 16 + m16] = make_float2(accR[mt][NP0 + np][r], accI[mt][NP0 + np][r]);
+    for (int i = tid; i < 15 * FT_LDP; i += 2 * BM) Pt[BM][i] = make_float2(0.0f, 0.0f);   // the spare rows (Pt[BM][..] runs on through them)
+}
+
+// one 32-column tile from the K loop to the store
+template <int BM>
+__device__ __forceinline__ void fused_f32_narrow_tile(const GemmTreeArgs& a, float* smem, float2 (*tw_lds)[CB_C], const FusedTile& T, bool inside,
+                                                      long long tile_lo, int tid, int stamp_slot) {
+    const int lane = tid & 63;
+    // the tile's combine twiddles (levels x 32 complex columns = 64 floats per level): a wave copies a level, a dword per lane
     const float* tw_src = reinterpret_cast<const float*>(a.comb_tw + T.G.tw_off + T.ntl * CB_C) + lane;   // level l: + l * tw_stride floats
     float* tw_dst = reinterpret_cast<float*>(&tw_lds[0][0]);
     const int tw_levels = T.G.levels_f, tw_stride = 2 * T.G.n_tiles * CB_C;
-    const long long s = a.base + T.G.s_rel;
-    const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
-    const float4* e_tile = a.E16 + (size_t)nt * (a.K / 2) * 16;
+    const float4* e_tile = a.E16 + (size_t)T.nt * (a.K / 2) * 16;
     f32x4a accR[2][2], accI[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -694,7 +808,7 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     }
     // a group's last column tile may hold 16 columns or fewer (3 of the 21 tiles at 48 kHz / 252 bins): half the MFMAs
     const bool half = T.ntl == T.G.n_tiles - 1 && T.G.n_cols - T.ntl * CB_C <= 16;
-    if (!(tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes))
+    if (!inside)
         fused_f32_kloop16_edge<BM>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     else if (half)
         fused_f32_kloop16<BM, true>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
@@ -707,22 +821,84 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     PVQ_STAMP(1);
     __syncthreads();   // the E slice is dead: the P' tile takes its place
     PVQ_STAMP(4);
-    // P' tile -> LDS as [row][32 complex + pad]  (C/D layout of the 16x16 MFMA: column = lane & 15, rows 4 (lane >> 4) + r)
-    float2 (*Pt)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);
-    {
-        const int m16 = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int np = 0; np < 2; ++np)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Pt[wave * 32 + mt * 16 + 4 * kq + r][np * 16 + m16] = make_float2(accR[mt][np][r], accI[mt][np][r]);
-        for (int i = tid; i < 15 * FT_LDP; i += 2 * BM) Pt[BM][i] = make_float2(0.0f, 0.0f);   // the spare rows (Pt[BM][..] runs on through them)
-    }
+    fused_dump_p<BM, 2, 0>(smem, accR, accI, tid);
     __syncthreads();
     PVQ_STAMP(5);
     fused_tree_store<BM>(smem, tw_lds, T, a, tid, stamp_slot);
+}
+
+
+// three more stamps per workgroup, behind the gridDim.x rows of eight: its first instruction, its last wave's last store issued, and that
+// store acknowledged — what lies between one workgroup's last and the next one's first is the dispatcher's (scripts/dev_conc.py)
+#define PVQ_END_STAMPS \
+    if (a.stamps) { \
+        unsigned long long* ends = a.stamps + (size_t)gridDim.x * 8 + (size_t)stamp_slot * 4; \
+        if (lane == 0) atomicMax(ends + 1, wall_clock64()); \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (lane == 0) atomicMax(ends + 2, wall_clock64()); \
+        if (tid == 0) ends[0] = t_entry; \
+    }
+template <int BM>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 (wide tiles: 64) complex columns
+__global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) {   // 4 waves per SIMD = two 512-thread (four 256-thread) workgroups per CU: at most 128 registers
+    constexpr bool WIDE = BM == 256;                   // (the 128-row form, a test shape, takes narrow tiles only)
+    constexpr int B_FLOATS = (WIDE ? 2 : 1) * FR_KC * FT_BN;   // a wide tile's two slices of E
+    constexpr int P_FLOATS = (BM + 15) * FT_LDP * 2;   // 15 spare rows: the register tree levels read their halo without a range check
+    __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice(s), then the P tile
+    __shared__ float2 tw_lds[2][FT_MAXL][CB_C];
+    const unsigned long long t_entry = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int4 entry = a.tile_list[blockIdx.x];   // .x: group | wide << 8
+    FusedTile T = fused_tile_of<BM>(a, make_int4(entry.x & 7, entry.y, entry.z, entry.w));   // (gv[8])
+    const bool wide = (entry.x >> 8) != 0;
+    if (T.f0 >= T.nfr) return;
+    const int stamp_slot = blockIdx.x;
+    PVQ_STAMP(0);
+    const long long s = a.base + T.G.s_rel;
+    const long long tile_lo = s + (long long)T.f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
+    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes;
+    if (WIDE && wide && inside) {
+        const float* tw_src = reinterpret_cast<const float*>(a.comb_tw + T.G.tw_off + T.ntl * CB_C) + lane;
+        float* tw_dst = reinterpret_cast<float*>(&tw_lds[0][0][0]);
+        const float4* e_tile = a.E16 + (size_t)T.nt * (a.K / 2) * 16;
+        f32x4a accR[2][4], accI[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int np = 0; np < 4; ++np)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accR[mt][np][r] = 0.0f;
+                    accI[mt][np][r] = 0.0f;
+                }
+        if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
+            a.clk[(blockIdx.x >> 6) * 4 + 0] = __builtin_amdgcn_s_memtime();
+            a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+        fused_f32_kloop64<BM>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, T.G.levels_f, 2 * T.G.n_tiles * CB_C, stamp_slot);
+        if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
+            a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
+            a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+        PVQ_STAMP(1);
+        // the two tiles' P' one after the other through the same buffer (the second waits in its accumulators)
+        __syncthreads();   // the E slices are dead
+        PVQ_STAMP(4);
+        fused_dump_p<BM, 4, 0>(smem, accR, accI, tid);
+        __syncthreads();
+        PVQ_STAMP(5);
+        fused_tree_store<BM>(smem, tw_lds[0], T, a, tid, stamp_slot);
+        __syncthreads();
+        fused_dump_p<BM, 4, 2>(smem, accR, accI, tid);
+        __syncthreads();
+        T.ntl += 1;
+        T.nt += 1;
+        fused_tree_store<BM>(smem, tw_lds[1], T, a, tid, stamp_slot);
+        PVQ_END_STAMPS
+        return;
+    }
+    // (the host pairs only tiles that lie inside the stream — same test, same numbers, launch(): the range-checked loop takes one tile)
+    fused_f32_narrow_tile<BM>(a, smem, tw_lds[0], T, inside, tile_lo, tid, stamp_slot);
+    PVQ_END_STAMPS
 }
 
 // Unfused form of the same GEMM (windows of more than 64 hop blocks: the tree runs as its own kernel over P' in memory):
@@ -2044,35 +2220,100 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             // runs on the XCD of all b' = b mod 8), and a queue takes its stripes in order, within a stripe every group's row tiles with
             // all their column tiles.  All window groups then read a stripe's PCM rows from that XCD's L2 while they are resident (once
             // per stripe, not once per group).  Entry: (group, column tile, first frame, position i * 8 + queue).
+            static const int FS = dev_knob("PVQ_TILE_FS", 2048);
+            static const int balance_env = dev_knob("PVQ_BALANCE", 1);   // 0: queues as the stripes fall
+            static const int order_env = dev_knob("PVQ_ORDER", 1);       // 0: wide and narrow tiles of a stripe interleaved
+            static const int wide_env = dev_knob("PVQ_WIDE", 1);         // 0: narrow tiles only; 2: wide tiles to the very end of every queue; 3: none in a queue's last stripe
+            const int wide_mode = !use_bf && fused_bm == 256 ? wide_env : 0;   // (the split-bf16 kernel and the 128-row form take 32-column tiles only)
             BlockDftTables::TileList* tl = nullptr;
             for (auto& c : t->tile_lists)
-                if (c.nf == (int)nf && c.bm == fused_bm) tl = &c;
+                if (c.nf == (int)nf && c.bm == fused_bm && c.wide == wide_mode && c.base == base && c.pcm_bytes == pcm_bytes) tl = &c;
             if (!tl) {
                 tl = &t->tile_lists[t->tile_list_next];
-                t->tile_list_next ^= 1;
-                static const int FS = dev_knob("PVQ_TILE_FS", 2048);
+                t->tile_list_next = (t->tile_list_next + 1) & 3;
                 std::vector<std::vector<int4>> q(8);
                 for (int g = 0; g < t->n_groups; ++g) {
                     const BlockGroup& G = t->groups[g];
                     const int S = fused_bm - G.nb_f + 1;
                     const int rows_g = (int)nf + G.nb - G.nb_f;
+                    const bool half_last = G.n_cols - (G.n_tiles - 1) * CB_C <= 16;
                     for (int f0 = 0; f0 < rows_g; f0 += S)
-                        for (int ntl = 0; ntl < G.n_tiles; ++ntl) q[(f0 / FS) & 7].push_back(make_int4(g, ntl, f0, f0 / FS));
+                        for (int ntl = 0; ntl < G.n_tiles; ++ntl) {
+                            // two neighbouring column tiles as one WIDE entry (.x bit 8; fp32 kernel, 256-row tiles), except a last tile of at
+                            // most 16 columns, which keeps its half-depth loop
+                            const long long tile_lo = base + G.s_rel + (long long)f0 * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
+                            const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)pcm_bytes;   // the kernel's own test
+                            const bool pair = wide_mode && inside && ntl + 1 < G.n_tiles && !(half_last && ntl + 1 == G.n_tiles - 1);
+                            q[(f0 / FS) & 7].push_back(make_int4(g | (pair ? 256 : 0), ntl, f0, f0 / FS));
+                            if (pair) ++ntl;
+                        }
                 }
                 size_t L = 0;
                 // what a tile costs its workgroup, roughly in us: K loop (half for a last tile of at most 16 columns) + tree levels
                 auto tile_cost = [&](const int4& e) {
-                    const BlockGroup& G = t->groups[e.x];
+                    const BlockGroup& G = t->groups[e.x & 255];
                     const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
-                    return (half ? 8 : 16) + G.levels_f;
+                    const long long tile_lo = base + G.s_rel + (long long)e.z * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
+                    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)pcm_bytes;
+                    if (!inside) return 2 * 16 + G.levels_f;   // the range-checked loop: dword loads
+                    return ((half ? 8 : 16) + G.levels_f) * (e.x >> 8 ? 2 : 1);
                 };
+                for (auto& v : q)   // by stripe; (group, row tile, column tile) order kept
+                    std::stable_sort(v.begin(), v.end(), [&](const int4& x, const int4& y) {
+                        if (x.w != y.w) return x.w < y.w;
+                        return order_env ? (x.x >> 8) > (y.x >> 8) : false;   // wide tiles of a stripe before its narrow ones (see below)
+                    });
+                // Even queues: stripes are dealt round robin, but the stream's first and last stripe carry extra tiles (the range-checked
+                // ones at the ends, which do not pair up, and the long windows' partial-sum rows past the last frame) — queue 0 ran 28 us
+                // longer than the rest of a 290 us launch.  The heaviest queue hands entries of its last stripe to the lightest until they
+                // differ by less than a tile (those read their PCM rows through another XCD's L2: a few dozen tiles per launch).
+                if (balance_env) {
+                    long long cost[8];
+                    for (int x = 0; x < 8; ++x) {
+                        cost[x] = 0;
+                        for (const int4& e : q[x]) cost[x] += tile_cost(e);
+                    }
+                    for (int it = 0; it < 4096; ++it) {
+                        int h = 0, l = 0;
+                        for (int x = 1; x < 8; ++x) {
+                            if (cost[x] > cost[h]) h = x;
+                            if (cost[x] < cost[l]) l = x;
+                        }
+                        if (q[h].empty()) break;
+                        int4 e = q[h].back();
+                        const int c = tile_cost(e);
+                        if (cost[h] - cost[l] <= c) break;
+                        q[h].pop_back();
+                        if (!q[l].empty()) e.w = q[l].back().w;   // it joins the receiving queue's last stripe
+                        q[l].push_back(e);
+                        cost[h] -= c;
+                        cost[l] += c;
+                    }
+                }
                 for (auto& v : q) {
-                    std::stable_sort(v.begin(), v.end(), [](const int4& x, const int4& y) { return x.w < y.w; });   // by stripe; (group, row tile, column tile) order kept
                     // the queue's last stripe: long tiles first, so that what is still running when the queues run dry is short
                     if (!v.empty()) {
                         const int last = v.back().w;
                         auto first_of_last = std::find_if(v.begin(), v.end(), [&](const int4& e) { return e.w == last; });
                         std::stable_sort(first_of_last, v.end(), [&](const int4& x, const int4& y) { return tile_cost(x) > tile_cost(y); });
+                        if (wide_mode == 1 || wide_mode == 3) {
+                            // ... and the queue's last entries narrow again (two per workgroup slot of the XCD; 3: the whole stripe): what is
+                            // still running when the queues run dry sets the launch's tail
+                            const size_t n_tail = wide_mode == 3 ? v.size() : 128;
+                            const size_t lo = first_of_last - v.begin();
+                            std::vector<int4> tail;
+                            while (v.size() > lo && tail.size() < n_tail) {
+                                const int4 e = v.back();
+                                v.pop_back();
+                                if (e.x >> 8) {
+                                    tail.push_back(make_int4(e.x & 255, e.y, e.z, e.w));
+                                    tail.push_back(make_int4(e.x & 255, e.y + 1, e.z, e.w));
+                                } else
+                                    tail.push_back(e);
+                            }
+                            std::stable_sort(tail.begin(), tail.end(), [&](const int4& x, const int4& y) { return tile_cost(x) > tile_cost(y); });
+                            v.insert(v.end(), tail.begin(), tail.end());
+                        }
                     }
                     L = std::max(L, v.size());
                 }
@@ -2093,6 +2334,9 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 PVQ_HIP(hipMemcpy(tl->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
                 tl->nf = (int)nf;
                 tl->bm = fused_bm;
+                tl->wide = wide_mode;
+                tl->base = base;
+                tl->pcm_bytes = pcm_bytes;
                 tl->blocks = (int)list.size();
             }
             fa.tile_list = tl->d;
@@ -2104,10 +2348,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.E16 = t->d_E16;
             static const char* stamps_env = dev_knob_str("PVQ_STAMPS");   // dump per-tile phase stamps of the first launch
             static bool stamps_done = false;
-            const bool do_stamps = stamps_env && !stamps_done;
+            static int stamps_skip = dev_knob("PVQ_STAMPS_SKIP", 0);         // ... of launch n + 1 (a warm one)
+            const bool do_stamps = stamps_env && !stamps_done && stamps_skip-- <= 0;
             fa.stamps = nullptr;
-            if (do_stamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&fa.stamps), (size_t)off * 8 * 8 + 8));
-            if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 8 * 8 + 8));
+            if (do_stamps) PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&fa.stamps), (size_t)off * 12 * 8 + 8));   // rows of 8, then rows of 4 (PVQ_END_STAMPS)
+            if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 12 * 8 + 8));
             // flop the GEMM's matrix instructions issue in this launch: tiles x rows x 64 real columns x depth x 2
             // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
             last_gemm_flop_ = eff_tiles * fused_bm * (2 * CB_C) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
@@ -2134,7 +2379,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             slot_end(SLOT_BLOCKDFT_GEMM, stream);
             if (do_stamps) {
                 stamps_done = true;
-                std::vector<unsigned long long> h((size_t)off * 8);
+                std::vector<unsigned long long> h((size_t)off * 12);
                 PVQ_HIP(hipStreamSynchronize(stream));
                 PVQ_HIP(hipMemcpy(h.data(), fa.stamps, h.size() * 8, hipMemcpyDeviceToHost));
                 PVQ_HIP(hipFree(fa.stamps));

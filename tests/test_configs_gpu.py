@@ -172,6 +172,37 @@ def test_two_handles_two_streams():
         assert torch.equal(x, y)
 
 
+def test_gemm_precision_switch_on_one_handle():
+    """One handle, one batch shape, fp32 -> split-bf16 -> fp32 GEMM arithmetic (what bench.py does for its `other_gemm` line): the
+    two kernels keep their tile lists apart (the fp32 kernel pairs column tiles into 64-column entries, the split-bf16 kernel takes
+    32-column tiles only), and each arithmetic gives the bits a fresh handle gives."""
+    pp, _ = get_geom("bench_48k_288")
+    hop, nf, n_lead = 256, 3000, 16128
+    pcm = torch.from_numpy(white_noise(n_lead + hop * nf, 5)).cuda()
+
+    def run(v):
+        db = torch.empty((nf, v.n_bins), device="cuda")
+        v.calculate_batch_db_device(pcm, hop, nf, db, n_lead=n_lead)
+        torch.cuda.synchronize()
+        return db.cpu().numpy()
+
+    v = P.Vqt.new(pp, 0)
+    v.set_algo(P.ALGO_BLOCKDFT)
+    a1 = run(v)
+    v.set_gemm_precision(P.GEMM_BF16X3)
+    b1 = run(v)
+    v.set_gemm_precision(P.GEMM_F32)
+    a2 = run(v)
+    w = P.Vqt.new(pp, 0)
+    w.set_algo(P.ALGO_BLOCKDFT)
+    w.set_gemm_precision(P.GEMM_BF16X3)
+    b0 = run(w)
+    assert np.array_equal(a1.view(np.uint32), a2.view(np.uint32))
+    assert np.array_equal(b1.view(np.uint32), b0.view(np.uint32))
+    loud = a1 > a1.max() - 40
+    assert np.abs(a1 - b1)[loud].max() <= 2e-2
+
+
 def test_unfused_fallback_stages_in_a_subprocess():
     """The unfused GEMM + combine stages (taken when a geometry has more than 8 window groups; developer knob
     PVQ_NO_FUSE=1) against the FFT path, in a child process because the knob is read once per process."""
@@ -209,9 +240,11 @@ def test_unfused_fallback_stages_in_a_subprocess():
 
 
 def test_tile_shapes_bit_identical_in_subprocesses():
-    """Both tile shapes of the hop-DFT + tree stage compute the same bits on every test geometry — same sums, same k order, same
-    tree levels: a frame's value must not depend on the tile that produced it.  256 x 32 rows (the product) and 128 x 32 rows
-    (PVQ_FUSED_BM=128, a knob of the developer library libpvq_dev.so), and the product library against the developer one.
+    """Every tile shape of the hop-DFT + tree stage computes the same bits on every test geometry — same sums, same k order, same
+    tree levels: a frame's value must not depend on the tile that produced it.  The product (256 rows, neighbouring column tiles
+    paired into 64-column wide tiles except at the stream's ends and in the launch's tail, queues evened out), 128 x 32 rows
+    (PVQ_FUSED_BM=128), 256 x 32 only (PVQ_WIDE=0, unbalanced queues), wide tiles wherever they fit (PVQ_WIDE=2) — knobs of the
+    developer library libpvq_dev.so — and the product library against the developer one.
     Child processes: the knobs are read once per process."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -240,13 +273,14 @@ def test_tile_shapes_bit_identical_in_subprocesses():
     """)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     res = {}
-    for tag, env in (("base", {}), ("dev", {"PVQ_DEV_LIB": "1"}), ("bm128", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "128"})):
+    for tag, env in (("base", {}), ("dev", {"PVQ_DEV_LIB": "1"}), ("bm128", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "128"}),
+                     ("narrow", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "0", "PVQ_BALANCE": "0"}), ("wide_all", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "2"})):
         f = os.path.join(root, "gpurun_out", f"forms_{tag}.npz")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0 and "FORM_OK" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = dict(np.load(f))
         os.remove(f)
-    for tag in ("dev", "bm128"):
+    for tag in ("dev", "bm128", "narrow", "wide_all"):
         for k, a in res["base"].items():
             assert np.array_equal(a.view(np.uint32), res[tag][k].view(np.uint32)), (tag, k)
 

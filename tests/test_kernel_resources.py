@@ -85,8 +85,9 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
         assert not bad, (name, bad[:5])
         n_checked += 1
     assert n_checked >= 8
-    # the fp32 K loop keeps a whole double k group of operand loads in flight: after issuing the next group's 8 loads it must not wait
-    # for fewer than 8 outstanding (vmcnt(N), N >= 8) before its first MFMA
+    # the fp32 K loops keep the operand loads of the NEXT stage in flight under the MFMAs of this one: a wait in a K loop body must never
+    # cover the group of loads issued last before it (vmcnt(N), N >= that group's size: 8 loads per double k group in the 32-column
+    # loop, 4 per stage in the 64-column one) — a wait for fewer means the loop runs without its prefetch distance
     for name, lines in body.items():
         if "blockdft_gemm_treeILi256" not in name:
             continue
@@ -99,16 +100,23 @@ def test_register_budgets_of_the_block_dft_kernels(tmp_path):
             elif t:
                 cur.append(t)
         blocks.append(cur)
-        hits = 0
-        for b in blocks:   # a K loop body: issues a double group of operand loads and MFMAs
-            loads = [i for i, t in enumerate(b) if t.startswith("buffer_load_dwordx4")]
-            if len(loads) < 8 or not any(t.startswith("v_mfma") for t in b):
+        hits, groups = 0, set()
+        for b in blocks:   # a K loop body: issues operand loads and MFMAs, and loops back to itself
+            n_loads = sum(t.startswith("buffer_load_dwordx4") for t in b)
+            if n_loads < 8 or not any(t.startswith("v_mfma") for t in b) or not any(t.startswith("s_cbranch") for t in b):
                 continue
-            waits = [t for t in b[loads[7]:] if t.startswith("s_waitcnt") and "vmcnt" in t]
-            assert waits, b[:3]
-            n = int(re.search(r"vmcnt\((\d+)\)", waits[0]).group(1))
-            assert n >= 8, (name, waits[0])
-            hits += 1
-        assert hits >= 4, hits
+            cyc = b + b   # (the loads at the end of the body precede the waits at its top)
+            for i in range(len(b), len(cyc)):
+                if not (cyc[i].startswith("s_waitcnt") and "vmcnt" in cyc[i]):
+                    continue
+                n = int(re.search(r"vmcnt\((\d+)\)", cyc[i]).group(1))
+                group, j = 0, i - 1
+                while j >= 0 and not (group and cyc[j].startswith("v_mfma")):
+                    group += cyc[j].startswith("buffer_load_dwordx4")
+                    j -= 1
+                assert group in (4, 8) and n >= group, (name, cyc[i], group)
+                groups.add(group)
+                hits += 1
+        assert hits >= 4 and groups == {4, 8}, (hits, groups)
     for u in find("blockdft_banddots4c_dbILi8ELi4ELi260ELi2"):
         assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u["ScratchSize"] == 0, u    # 8 waves x 2 workgroups per CU
