@@ -115,6 +115,7 @@ struct BlockDftTables {
     struct TileList {
         int4* d = nullptr; size_t cap = 0;
         int nf = -1, bm = 0, wide = 0, blocks = 0;
+        double eff_tiles = 0.0;                       // MFMA work of the list in whole 32-column tiles
         long long base = 0; unsigned pcm_bytes = 0;   // where the stream starts and ends relative to the tiles: which tiles may pair up (wide entries)
     } tile_lists[4];   // four slots: a batch's first, middle and last sub-batch alternate without rebuilding
     int tile_list_next = 0;
@@ -2223,6 +2224,8 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             static const int FS = dev_knob("PVQ_TILE_FS", 2048);
             static const int balance_env = dev_knob("PVQ_BALANCE", 1);   // 0: queues as the stripes fall
             static const int order_env = dev_knob("PVQ_ORDER", 1);       // 0: wide and narrow tiles of a stripe interleaved
+            static const int pair_half_env = dev_knob("PVQ_PAIR_HALF", 0); // 1: a group's last tile of at most 16 columns pairs up too (measured: same time, more MFMAs)
+            static const int tail_env = dev_knob("PVQ_TAIL", 128);       // narrow entries at the end of every queue
             static const int wide_env = dev_knob("PVQ_WIDE", 1);         // 0: narrow tiles only; 2: wide tiles to the very end of every queue; 3: none in a queue's last stripe
             const int wide_mode = !use_bf && fused_bm == 256 ? wide_env : 0;   // (the split-bf16 kernel and the 128-row form take 32-column tiles only)
             BlockDftTables::TileList* tl = nullptr;
@@ -2239,11 +2242,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     const bool half_last = G.n_cols - (G.n_tiles - 1) * CB_C <= 16;
                     for (int f0 = 0; f0 < rows_g; f0 += S)
                         for (int ntl = 0; ntl < G.n_tiles; ++ntl) {
-                            // two neighbouring column tiles as one WIDE entry (.x bit 8; fp32 kernel, 256-row tiles), except a last tile of at
-                            // most 16 columns, which keeps its half-depth loop
+                            // two neighbouring column tiles as one WIDE entry (.x bit 8; fp32 kernel, 256-row tiles)
                             const long long tile_lo = base + G.s_rel + (long long)f0 * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
                             const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)pcm_bytes;   // the kernel's own test
-                            const bool pair = wide_mode && inside && ntl + 1 < G.n_tiles && !(half_last && ntl + 1 == G.n_tiles - 1);
+                            // (a last tile of at most 16 columns keeps its own entry and its half-depth loop)
+                            const bool pair = wide_mode && inside && ntl + 1 < G.n_tiles && (pair_half_env || !(half_last && ntl + 1 == G.n_tiles - 1));
                             q[(f0 / FS) & 7].push_back(make_int4(g | (pair ? 256 : 0), ntl, f0, f0 / FS));
                             if (pair) ++ntl;
                         }
@@ -2299,7 +2302,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                         if (wide_mode == 1 || wide_mode == 3) {
                             // ... and the queue's last entries narrow again (two per workgroup slot of the XCD; 3: the whole stripe): what is
                             // still running when the queues run dry sets the launch's tail
-                            const size_t n_tail = wide_mode == 3 ? v.size() : 128;
+                            const size_t n_tail = wide_mode == 3 ? v.size() : (size_t)tail_env;
                             const size_t lo = first_of_last - v.begin();
                             std::vector<int4> tail;
                             while (v.size() > lo && tail.size() < n_tail) {
@@ -2317,6 +2320,13 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     }
                     L = std::max(L, v.size());
                 }
+                tl->eff_tiles = 0.0;
+                for (auto& v : q)
+                    for (const int4& e : v) {
+                        const BlockGroup& G = t->groups[e.x & 255];
+                        const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
+                        tl->eff_tiles += (e.x >> 8) ? 2.0 : (half ? 0.5 : 1.0);   // (the few range-checked tiles run the full loop: counted as half all the same)
+                    }
                 std::vector<int4> list(8 * std::max<size_t>(L, 1), make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
                 for (int x = 0; x < 8; ++x) {
                     for (size_t i = 0; i < q[x].size(); ++i) {
@@ -2355,6 +2365,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             if (do_stamps) PVQ_HIP(hipMemset(fa.stamps, 0, (size_t)off * 12 * 8 + 8));
             // flop the GEMM's matrix instructions issue in this launch: tiles x rows x 64 real columns x depth x 2
             // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
+            if (!use_bf) eff_tiles = tl->eff_tiles;   // (what the list's entries issue: a wide entry two whole tiles, a lone half tile half a tile)
             last_gemm_flop_ = eff_tiles * fused_bm * (2 * CB_C) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
             fa.clk = nullptr;
             if (profiling_ && !use_bf) {
