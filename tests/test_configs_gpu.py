@@ -268,6 +268,18 @@ def test_tile_shapes_bit_identical_in_subprocesses():
             torch.cuda.synchronize()
             out[name + "_db"] = db.cpu().numpy()
             out[name + "_cx"] = cx.cpu().numpy()
+        # other hops on one geometry: 64 (one double k group per tile: the K loops' shortest form), 512 and 1024 (the slice of E is
+        # staged in two / four passes; 1024 = the shortest window: no tree level at all in its group)
+        pp, op = get_geom("bench_48k_252")
+        for hop in (64, 512, 1024):
+            v = P.Vqt.new(pp, 0)
+            v.set_algo(P.ALGO_BLOCKDFT)
+            nf, n_lead = 40000 // (hop // 64), 333
+            pcm = torch.from_numpy(white_noise(n_lead + hop * nf, 13)).cuda()
+            db = torch.empty((nf, v.n_bins), device="cuda")
+            v.calculate_batch_db_device(pcm, hop, nf, db, n_lead=n_lead)
+            torch.cuda.synchronize()
+            out["hop%d_db" % hop] = db.cpu().numpy()
         np.savez(sys.argv[1], **out)
         print("FORM_OK")
     """)

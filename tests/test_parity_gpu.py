@@ -131,6 +131,26 @@ def test_batch_parity_noise(name, algo):
     assert_parity(db, cx, wdb, wcx)
 
 
+@pytest.mark.parametrize("hop,nf", [(64, 1200), (128, 900), (512, 700), (1024, 600)])
+def test_blockdft_other_hops_vs_oracle(hop, nf):
+    """The block-DFT path at the hops the other tests do not use (they run 256, and 128 at 96 kHz): 64 = one double k group per tile
+    and windows of 128 hop blocks (partial sums + blockdft_tree_finish), 512 / 1024 = the slice of E staged in two / four passes,
+    1024 = the shortest window (a group without any tree level).  Batches long enough for tiles that lie wholly inside the stream
+    (the 64-column wide tiles and the 16-byte operand loads), with a lead that is no multiple of anything."""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    ov = O.OracleVqt(op)
+    n_lead = 4321
+    if not _applicable(v, P.ALGO_BLOCKDFT, hop, nf):
+        pytest.skip("block-DFT path not applicable to this hop")
+    algo_id = _set_algo(v, P.ALGO_BLOCKDFT)
+    pcm = white_noise(n_lead + hop * nf, 0xB10C + hop)
+    db, cx = run_gpu(v, pcm, hop, nf, n_lead)
+    assert v.last_algo() == algo_id
+    wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
+    assert_parity(db, cx, wdb, wcx)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_three_regimes_and_stream_start(algo):
     """silent / clip-branch / shift-branch frames (vqt.rs:939-951), starting from an empty ring
