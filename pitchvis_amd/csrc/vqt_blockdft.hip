@@ -2374,9 +2374,9 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     if (t->d_clk) PVQ_HIP(hipFree(t->d_clk));
                     t->d_clk = nullptr; t->clk_cap = 0;
                     PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_clk), need));
+                    PVQ_HIP(hipMemset(t->d_clk, 0, need));   // once: every sampled workgroup rewrites its slot at every launch (a fill per launch cost the stream 3 us)
                     t->clk_cap = need;
                 }
-                PVQ_HIP(hipMemsetAsync(t->d_clk, 0, need, stream));
                 t->clk_n = off / 64 + 1;
                 fa.clk = t->d_clk;
             }
