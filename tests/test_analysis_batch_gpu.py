@@ -149,6 +149,37 @@ def test_gpu_streams_follow_the_host_state(bpo, octaves, n_streams, n_frames, mo
         assert exact[k][0] >= 0.999 * exact[k][1], (k, exact[k])
 
 
+def test_per_frame_durations():
+    """frame_times_ns: a different frame_time per call of preprocess (analysis.rs:288 takes it per frame: a live consumer passes the
+    time since its last frame) — jittered 8 ... 30 ms here; the recurrence state must follow the host object fed the same durations."""
+    rng_ = P.VqtRange(55.0, 7, 36)
+    nb, n_streams, n_frames = 252, 6, 240
+    x = _frames(n_streams, n_frames, nb, 77)
+    times = np.random.default_rng(5).uniform(0.008, 0.030, n_frames)
+    times = np.round(times * 1e9) / 1e9   # whole nanoseconds: what crosses the ABI
+    b = P.AnalysisBatch(rng_, n_streams)
+    outs = {k: torch.zeros((n_streams, n_frames, nb), device="cuda") for k in ("x_vqt_smoothed", "calmness", "x_vqt_afterglow")}
+    outs["scene_calmness"] = torch.zeros((n_streams, n_frames), device="cuda")
+    b.preprocess_device(torch.from_numpy(x).cuda(), n_frames, 0.0, outs, frame_times=list(times))
+    torch.cuda.synchronize()
+    g = {k: t.cpu().numpy() for k, t in outs.items()}
+    same = total = 0
+    for s in range(n_streams):
+        st = P.AnalysisState.new(rng_)
+        for f in range(n_frames):
+            st.preprocess(x[s, f], float(times[f]))
+            for k in ("x_vqt_smoothed", "calmness", "x_vqt_afterglow"):
+                a, w = g[k][s, f], np.asarray(getattr(st, k), np.float32)
+                # the EMA weights are 1 - exp(-2 dt / horizon): the device rounds a double exp once, the host calls libm's expf, and with
+                # thousands of distinct (dt, horizon) pairs the two differ by one ulp now and then (first at frame 34 here); the state
+                # then follows within a few ulp
+                assert np.allclose(a, w, rtol=2e-6, atol=2e-6), (s, f, k, np.abs(a - w).max())
+                same += int((a.view(np.uint32) == w.view(np.uint32)).sum())
+                total += a.size
+            assert abs(g["scene_calmness"][s, f] - np.float32(st.smoothed_scene_calmness)) <= 2e-6, (s, f)
+    assert same >= 0.98 * total, (same, total)
+
+
 def test_batch_rejects_what_it_cannot_do():
     with pytest.raises(P.PvqError):
         P.AnalysisBatch(P.VqtRange(55.0, 7, 36), 4, device=-1)      # no CPU fallback
