@@ -9,13 +9,21 @@ BASELINE.json configs[1], "65 536-hop batch of 48 kHz mono white noise", geometr
 VqtParameters{sr 48000, n_fft 32768, range{55 Hz, 7 oct, 36 bins/oct}, sparsity 0.999, Q 1.6,
 gamma 7.68}, hop 256, 252 bins, fp32.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU) runs BASELINE.json configs[2]: ONE
-hop stream of N x 131 072 hops (1 M hops at N = 8) of white noise, seed 0x5EED0003, generated
-identically on every rank, geometry 8 octaves x 36 = 288 bins, hop 256; rank r takes the
-contiguous frame range plan_shard gives it together with its real window-union halo (the
-16 128 samples before its first hop); kernel tables are replicated; there is no collective on
-the data path.  Weak scaling: every rank processes F frames,
+`value` is measured on THAT workload at every N (BASELINE.json quotes its metric on 48 kHz / hop 256 /
+252 bins), so that the driver's 1 -> 8 curve compares like with like: N > 1 (launched by
+torch.distributed.run, one rank per GPU) analyses ONE hop stream of N x 65 536 hops of the same
+white noise (a counter-based function of (seed, sample index), so every rank generates exactly its
+own piece); rank r takes the contiguous frame range plan_shard gives it together with its real
+window-union halo (the 16 128 samples before its first hop); kernel tables are replicated; there
+is no collective on the data path.  Weak scaling: every rank processes F frames,
 value = N*F*K / max-over-ranks time.
+
+BASELINE.json configs[2] ("1 M-hop batch sharded across 8 x MI355X, 8 octaves x 36 bins/oct":
+288 bins, 131 072 hops per GPU, seed 0x5EED0003, real halos) is measured in the same run in a
+timed region of its own (same K steps, same barriers, max over ranks) and reported under the
+extra key "config2" of the same line — at N = 1 too ("one GPU's share"), so that either
+workload's efficiency can be computed from per-N values of ONE workload.  `--config 2` makes
+configs[2] the headline instead (developer use).
 
 Rank 0 prints ONE JSON line.
 """
@@ -163,14 +171,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=0, help="frames (hops) per GPU per step (default: 65 536 at N = 1, 131 072 at N > 1)")
+    ap.add_argument("--frames", type=int, default=0, help="frames (hops) per GPU per step (default: the configuration's own — 65 536 for configs[1], 131 072 for configs[2])")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2],
-                    help="BASELINE config to run: 1 (252 bins, the N = 1 default) or 2 (288 bins, one sharded stream: the N > 1 default)")
+                    help="BASELINE config the headline `value` is measured on: 1 (252 bins, 65 536 hops per GPU: the default at EVERY N, what "
+                         "BASELINE.json's metric is quoted on) or 2 (288 bins, 131 072 hops per GPU); the other one is reported under an extra key")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "blockdft"])
     ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the block-DFT GEMM / kernel product: fp32 MFMA (default, the library default) or the exact "
                          "3-way bf16 split on the bf16 matrix cores; the other one is measured too and reported as alt_gemm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-config", action="store_true", help="skip the second BASELINE configuration (the extra key config2 / config1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the plumbing on one GPU)")
     args = ap.parse_args()
@@ -210,87 +220,103 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
-    W = WORKLOADS[args.config or (2 if world > 1 else 1)]
-    N_BINS = W["n_bins"]
+    def measure(W, F, with_alt):
+        """one workload, this rank's shard: warm-up, then EXACTLY args.steps timed steps between barrier + synchronize on both sides
+        (max over ranks), then the untimed per-kernel passes"""
+        n_bins = W["n_bins"]
+        params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, W["octaves"], 36))
+        vqt = P.Vqt.new(params, device=device_index)
+        vqt.set_algo({"auto": P.ALGO_AUTO, "fft": P.ALGO_FFT, "blockdft": P.ALGO_BLOCKDFT}[args.algo])
+        vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
+        assert vqt.n_bins == n_bins
+        # this rank's shard of ONE world*F-frame stream: its hops plus the window-union halo that precedes them.  The stream is a
+        # counter-based function of (seed, sample index), so every rank computes exactly its own piece — halo included — of one
+        # signal without materialising the rest (configs[2] at N = 8: the whole stream is 1 GiB).
+        shard = plan_shard(world * F, HOP, vqt.window_union, rank, world)
+        assert shard.n_frames == F
+        d_pcm = stream_slice(W["seed"], shard.sample_begin, shard.sample_end, "cuda")
+        torch.cuda.empty_cache()
+        d_db = torch.empty((F, n_bins), device="cuda", dtype=torch.float32)
+        words = (n_bins + 31) // 32
+        max_peaks = 64
+        d_mask = torch.zeros((F, words), device="cuda", dtype=torch.int32)
+        d_cnt = torch.zeros(F, device="cuda", dtype=torch.int32)
+        d_ctr = torch.zeros((F, max_peaks), device="cuda", dtype=torch.float32)
+        d_sz = torch.zeros((F, max_peaks), device="cuda", dtype=torch.float32)
+
+        def step():
+            vqt.vqt_analyze_batch_device(d_pcm, HOP, shard.n_frames, d_db, d_mask, d_cnt, d_ctr, d_sz, max_peaks,
+                                         n_lead=shard.n_lead)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        vqt.set_profiling(2)   # HIP events around the dominant kernel's launches only, on the launch stream (every event record costs the stream ~3 us: the other kernels are timed in an untimed pass below)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kernel_ms_main = vqt.last_kernel_ms()   # the dominant kernel, measured inside the timed region
+        # every kernel of a step, in an extra untimed pass of the same steps
+        vqt.set_profiling(True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        kernel_ms = vqt.last_kernel_ms()
+        kernel_n = vqt.last_kernel_launches()
+        kernel_ms.update(kernel_ms_main)
+        r = dict(vqt=vqt, shard=shard, n_bins=n_bins, F=F, kernel_ms=kernel_ms, kernel_n=kernel_n, fpl=vqt.last_frames_per_launch(),
+                 gemm_flop=vqt.last_gemm_flop(),     # flop the matrix instructions of one GEMM launch issue (tiles x 256 x 64 x depth x 2)
+                 sclk_mhz=vqt.last_sclk_mhz(),       # shader clock inside the GEMM kernel's K loop, sampled during the timed launches
+                 algo=vqt.last_algo())
+        vqt.set_profiling(False)
+        if with_alt:
+            # the other GEMM arithmetic, same workload, reported beside the headline (rank-local, not part of `value`)
+            other = "f32" if args.gemm == "bf16x3" else "bf16x3"
+            vqt.set_gemm_precision(P.GEMM_F32 if other == "f32" else P.GEMM_BF16X3)
+            step()
+            torch.cuda.synchronize()
+            vqt.set_profiling(True)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            r.update(other=other, dt_other=time.perf_counter() - t1, kernel_ms_other=vqt.last_kernel_ms())
+            vqt.set_profiling(False)
+            vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
+        if world > 1:
+            t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        r["dt"] = dt
+        # sanity: the output is real (not skipped work)
+        assert torch.isfinite(d_db).all() and float(d_db.max()) > 0.0 and int(d_cnt.sum()) > 0
+        return r
+
+    # The headline: BASELINE configs[1] (what BASELINE.json's metric is quoted on) at EVERY N, unless --config 2 asks otherwise
+    main_cfg = args.config or 1
+    W = WORKLOADS[main_cfg]
+    R = measure(W, args.frames or W["frames"], with_alt=True)
+    # ... and the other BASELINE bench configuration in a timed region of its own, for the extra key
+    other_cfg = 2 if main_cfg == 1 else 1
+    W2 = WORKLOADS[other_cfg]
+    F2 = args.frames or W2["frames"]
+    R2 = None if args.no_extra_config else measure(W2, F2, with_alt=False)
+    vqt, N_BINS, F, dt = R["vqt"], R["n_bins"], R["F"], R["dt"]
+    kernel_ms, kernel_n, fpl, gemm_flop, sclk_mhz = R["kernel_ms"], R["kernel_n"], R["fpl"], R["gemm_flop"], R["sclk_mhz"]
+    other, dt_other, kernel_ms_other = R["other"], R["dt_other"], R["kernel_ms_other"]
     F_ALG_FLOP_PER_FRAME, B_ALG_BYTES_PER_FRAME = W["f_alg"], W["b_alg"]
-    params = P.VqtParameters(sr=SR, range=P.VqtRange(55.0, W["octaves"], 36))
-    vqt = P.Vqt.new(params, device=device_index)
-    vqt.set_algo({"auto": P.ALGO_AUTO, "fft": P.ALGO_FFT, "blockdft": P.ALGO_BLOCKDFT}[args.algo])
-    vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
-    assert vqt.n_bins == N_BINS
-
-    # this rank's shard of ONE world*F-frame stream: its hops plus the window-union halo that precedes them.  The stream is a
-    # counter-based function of (seed, sample index), so every rank computes exactly its own piece — halo included — of one
-    # signal without materialising the rest (at N = 8 the whole stream is 1 GiB).
-    F = args.frames or W["frames"]
-    shard = plan_shard(world * F, HOP, vqt.window_union, rank, world)
-    assert shard.n_frames == F
-    d_pcm = stream_slice(W["seed"], shard.sample_begin, shard.sample_end, "cuda")
-    torch.cuda.empty_cache()
-    d_db = torch.empty((F, N_BINS), device="cuda", dtype=torch.float32)
-    words = (N_BINS + 31) // 32
-    max_peaks = 64
-    d_mask = torch.zeros((F, words), device="cuda", dtype=torch.int32)
-    d_cnt = torch.zeros(F, device="cuda", dtype=torch.int32)
-    d_ctr = torch.zeros((F, max_peaks), device="cuda", dtype=torch.float32)
-    d_sz = torch.zeros((F, max_peaks), device="cuda", dtype=torch.float32)
-
-    def step():
-        vqt.vqt_analyze_batch_device(d_pcm, HOP, shard.n_frames, d_db, d_mask, d_cnt, d_ctr, d_sz, max_peaks,
-                                     n_lead=shard.n_lead)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    vqt.set_profiling(2)   # HIP events around the dominant kernel's launches only, on the launch stream (every event record costs the stream ~3 us: the other kernels are timed in an untimed pass below)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kernel_ms_main = vqt.last_kernel_ms()   # the dominant kernel, measured inside the timed region
-    # every kernel of a step, in an extra untimed pass of the same steps
-    vqt.set_profiling(True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    kernel_ms = vqt.last_kernel_ms()
-    kernel_n = vqt.last_kernel_launches()
-    kernel_ms.update(kernel_ms_main)
-    fpl = vqt.last_frames_per_launch()
-    gemm_flop = vqt.last_gemm_flop()     # flop the matrix instructions of one GEMM launch issue (tiles x 256 x 64 x depth x 2)
-    sclk_mhz = vqt.last_sclk_mhz()       # shader clock inside the GEMM kernel's K loop, sampled during the timed launches
-    vqt.set_profiling(False)
-    # the other GEMM arithmetic, same workload, reported beside the headline (rank-local, not part of `value`)
-    other = "f32" if args.gemm == "bf16x3" else "bf16x3"
-    vqt.set_gemm_precision(P.GEMM_F32 if other == "f32" else P.GEMM_BF16X3)
-    step()
-    torch.cuda.synchronize()
-    vqt.set_profiling(True)
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt_other = time.perf_counter() - t1
-    kernel_ms_other = vqt.last_kernel_ms()
-    vqt.set_profiling(False)
-    vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
-    if world > 1:
-        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
         total_frames = world * F * args.steps
         value = total_frames / dt
-        # sanity: the output is real (not skipped work)
-        assert torch.isfinite(d_db).all() and float(d_db.max()) > 0.0 and int(d_cnt.sum()) > 0
         # dominant kernel = largest total GPU time; one launch of it processes `fpl` frames
         dom = max(kernel_ms.items(), key=lambda kv: kv[1] * kernel_n.get(kv[0], 1))
         dom_s = dom[1] * 1e-3
@@ -399,6 +425,26 @@ def main():
             "ms_per_step": round(dt_other / args.steps * 1e3, 4),
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms_other.items()},
         }
+        if R2 is not None:
+            # the other BASELINE bench configuration, same run, same K steps and barriers, its own timed region
+            dom2 = max(R2["kernel_ms"].items(), key=lambda kv: kv[1] * R2["kernel_n"].get(kv[0], 1))
+            exec2 = R2["gemm_flop"] / (dom2[1] * 1e-3) / 1e12 if dom2[0] == "blockdft_gemm" and R2["gemm_flop"] > 0 else None
+            key = f"config{other_cfg}" + ("_single_gpu" if world == 1 else "")
+            out[key] = {
+                "workload": W2["name"].format(F=F2, T=world * F2, N=world),
+                "value": round(world * F2 * args.steps / R2["dt"], 1),
+                "unit": "frames/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "ms_per_step": round(R2["dt"] / args.steps * 1e3, 4),
+                "frames_per_gpu_per_step": F2,
+                "n_bins": R2["n_bins"],
+                "scaling": "weak",
+                "kernel_ms_per_launch": {k: round(v, 4) for k, v in R2["kernel_ms"].items()},
+                "roofline_frac": round(exec2 / PEAK_FP32_TFLOPS, 5) if exec2 is not None and args.gemm == "f32" else None,
+                "note": "same run, its own timed region (barrier + synchronize on both sides, max over ranks); scaling efficiency of "
+                        "this workload = its value at N / (N x its value at N = 1, reported as config2_single_gpu in the N = 1 line)",
+            }
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -11,10 +11,10 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (the program goes directly after `--`: no env / bash -c hop under rocprofv3)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-config > $OUT/${TAG}_stats.log 2>&1
 for cfg in 1 2; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc${cfg}_$c -- python3 $ROOT/bench.py --steps 3 --warmup 1 --config $cfg --no-cpu-baseline > $OUT/${TAG}_pmc${cfg}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc${cfg}_$c -- python3 $ROOT/bench.py --steps 3 --warmup 1 --config $cfg --no-cpu-baseline --no-extra-config > $OUT/${TAG}_pmc${cfg}_$c.log 2>&1
   done
 done
 i=0
@@ -23,7 +23,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM" \
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_sq$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_sq$i.log 2>&1 || echo "SQ pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_sq$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-config > $OUT/${TAG}_sq$i.log 2>&1 || echo "SQ pass $i failed"
 done
 cd $ROOT
 python3 - <<PY
@@ -82,5 +82,5 @@ PY
 # the bench lines LAST: they attach the traffic capture just taken on this build (profiles/traffic_latest.json on this box)
 cp $OUT/traffic_latest.json $ROOT/profiles/traffic_latest.json
 python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python3 $ROOT/bench.py --steps 10 --warmup 3 --config 2 --no-cpu-baseline > $OUT/${TAG}_bench_config2.json 2>> $OUT/${TAG}_bench.err
+python3 $ROOT/bench.py --steps 10 --warmup 3 --config 2 --no-cpu-baseline --no-extra-config > $OUT/${TAG}_bench_config2.json 2>> $OUT/${TAG}_bench.err
 cat $OUT/${TAG}_bench.json

@@ -388,20 +388,35 @@ def test_config3_full_size_shard_on_one_gpu():
 
 def test_bench_two_ranks_gloo_on_one_gpu():
     """bench.py's N > 1 path end to end on the one-GPU box: two ranks (both on cuda:0, gloo for the barrier and the
-    max-over-ranks reduce) run BASELINE configs[2]'s geometry on two consecutive shards of one stream.  The 8-GPU RCCL run
-    is the driver's; this checks that the line it will get is well-formed and names the right workload."""
+    max-over-ranks reduce) on two consecutive shards of one stream.  The 8-GPU RCCL run is the driver's; this checks that the
+    line it will get is well-formed and that `value` at N = 2 is measured on the SAME workload as at N = 1 (BASELINE
+    configs[1], what the metric is quoted on: a 1 -> 8 curve must compare like with like), with configs[2] under its extra key."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    common = ["--steps", "3", "--warmup", "1", "--frames", "16384"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--frames", "16384", "--backend", "gloo"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["n_bins"] == 288 and "configs[2]" in j["config"]["workload"]
-    assert j["value"] > 0 and 0 < j["roofline"]["frac"] <= 1.0 and j["roofline"]["bound"] == "mfma"
-    assert abs(j["value"] - 2 * 16384 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline"] + common, capture_output=True, text=True,
+                        timeout=600, cwd=root)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    # the headline of both lines is BASELINE configs[1], word for word the same workload
+    assert j["config"]["workload"] == j1["config"]["workload"] == bench.WORKLOADS[1]["name"].format(F=16384, T=0, N=0)
+    assert "configs[1]" in j["config"]["workload"] and j["config"]["n_bins"] == j1["config"]["n_bins"] == 252
+    assert j["n_gpus"] == 2 and j1["n_gpus"] == 1 and j["scaling"] == j1["scaling"] == "weak"
+    assert j["config"]["frames_per_gpu_per_step"] == j1["config"]["frames_per_gpu_per_step"] == 16384
+    for line, n in ((j, 2), (j1, 1)):
+        assert line["value"] > 0 and 0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] == "mfma"
+        assert abs(line["value"] - n * 16384 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-3
+    # configs[2] rides along under its own key, on the same N
+    c2, c21 = j["config2"], j1["config2_single_gpu"]
+    assert c2["n_bins"] == c21["n_bins"] == 288 and "configs[2]" in c2["workload"] and c2["n_gpus"] == 2 and c21["n_gpus"] == 1
+    assert abs(c2["value"] - 2 * 16384 * 3 / (c2["ms_per_step"] * 3e-3)) / c2["value"] < 1e-3
