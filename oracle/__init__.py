@@ -92,6 +92,8 @@ def lib():
         L.orc_analyze_frame.restype = C.c_uint32
         L.orc_expf.argtypes = [C.c_float]; L.orc_expf.restype = C.c_float
         L.orc_powf.argtypes = [C.c_float, C.c_float]; L.orc_powf.restype = C.c_float
+        L.orc_expf_v.argtypes = [fp, C.c_uint32, fp]
+        L.orc_powf_v.argtypes = [C.c_float, fp, C.c_uint32, fp]
         L.orc_fft_complex.argtypes = [fp, C.c_uint32, C.c_int]
         L.orc_fft_real.argtypes = [fp, C.c_uint32, fp]
         _lib = L
@@ -318,3 +320,18 @@ def expf(x) -> np.float32:
 
 def powf(x, y) -> np.float32:
     return np.float32(lib().orc_powf(float(np.float32(x)), float(np.float32(y))))
+
+
+def expf_v(x) -> np.ndarray:
+    """glibc expf over an f32 array (the same call as expf, per element)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_expf_v(_f(x), x.size, _f(out))
+    return out
+
+
+def powf_v(base, y) -> np.ndarray:
+    y = np.ascontiguousarray(y, np.float32)
+    out = np.empty_like(y)
+    lib().orc_powf_v(float(np.float32(base)), _f(y), y.size, _f(out))
+    return out

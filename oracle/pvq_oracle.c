@@ -807,3 +807,6 @@ uint32_t orc_analyze_frame(const float *vqt, uint32_t n, float min_freq, uint32_
  * evaluates exp / pow with the same glibc routines the reference's f32::exp / f32::powf resolve to */
 float orc_expf(float x) { return expf(x); }
 float orc_powf(float x, float y) { return powf(x, y); }
+/* the same libm calls over arrays (oracle/analysis_state.py's vectorised form: one call per frame instead of one per bin) */
+void orc_expf_v(const float *x, uint32_t n, float *out) { for (uint32_t i = 0; i < n; ++i) out[i] = expf(x[i]); }
+void orc_powf_v(float base, const float *y, uint32_t n, float *out) { for (uint32_t i = 0; i < n; ++i) out[i] = powf(base, y[i]); }

@@ -129,6 +129,8 @@ uint32_t orc_analyze_frame(const float *vqt, uint32_t n, float min_freq, uint32_
 /* glibc expf / powf (used by oracle/analysis_state.py) */
 float orc_expf(float x);
 float orc_powf(float x, float y);
+void orc_expf_v(const float *x, uint32_t n, float *out);
+void orc_powf_v(float base, const float *y, uint32_t n, float *out);
 
 /* FFT contracts (vqt.rs:1087-1128): unnormalised complex forward/inverse, R2C */
 void orc_fft_complex(float *re_im_interleaved, uint32_t n, int inverse);
