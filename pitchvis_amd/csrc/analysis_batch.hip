@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "peaks_device.hpp"
@@ -34,6 +35,7 @@ struct AbArgs {
     const float* db;   // [n_streams][n_frames][n_bins]
     int n_streams, n_frames, n_bins, bpo, octaves;
     float min_freq;
+    float log2_min_freq;   // log2f(min_freq), host libm (peak_detection.rs:205)
     float peak_prom, peak_h, bass_prom, bass_h;
     int highest_bassnote;
     float harm_thr;
@@ -43,12 +45,20 @@ struct AbArgs {
     unsigned long long note_ns, scene_ns, tuning_ns;
     unsigned long long frame_ns;
     const unsigned long long* frame_times;   // optional, [n_frames]
+    // EMA weights 1 - exp(-2 dt / horizon) from the HOST's libm, one row per distinct frame time of the call (alpha_tab): the row is
+    // (alpha_note, alpha_scene, alpha_tuning, -, alpha[horizon = 0 .. tab_n - 1 whole ms]): analysis.rs:301-323 truncates a bin's
+    // horizon to whole milliseconds, so a few hundred values cover every bin of every frame.  frame_row: the row of each frame
+    // (null: row 0 for all).  alpha_tab null: the weights are evaluated here (double exp, rounded once).
+    const float* alpha_tab;
+    const uint32_t* frame_row;
+    int tab_n, tab_stride;
     const float* lnf;
     int dist, min_bin, radius;
     float *smoothed, *calm, *released, *afterglow, *peakfiltered, *pitch_acc, *pitch_dev, *scene, *tuning;   // state
     AnalysisBatchOutputs o;
-    unsigned scratch_bytes;   // peaks_scratch_bytes(n_bins, dist)
+    unsigned scratch_bytes;   // per-wave scratch of the peak routines: max(peaks_scratch_bytes, peaks_lean_scratch_bytes)
     unsigned wave_bytes;      // LDS bytes per wave
+    int generic_peaks;        // developer build: 1 = the generic peak routine for every frame (A/B against the lean one)
 };
 
 namespace {
@@ -56,7 +66,10 @@ namespace {
 __device__ __forceinline__ float ab_exp(float x) { return (float)exp((double)x); }
 __device__ __forceinline__ float ab_log2(float x) { return (float)log2((double)x); }
 __device__ __forceinline__ float ab_log10(float x) { return (float)log10((double)x); }
-__device__ __forceinline__ float ab_pow(float b, float y) { return (float)pow((double)b, (double)y); }
+__device__ __forceinline__ float ab_exp2(float x) { return (float)exp2((double)x); }   // 2.0_f32.powf(x)
+// 10.0_f32.powf(y): 2^(y log2 10) in double (the product's rounding error, ~1e-15 relative after the exp2, is eight orders below
+// half an f32 ulp) — a double exp2 costs a quarter of a double pow
+__device__ __forceinline__ float ab_pow10(float y) { return (float)exp2((double)y * 3.321928094887362347870319429489390175865); }
 // core::time::Duration::as_secs_f32 (analysis_host.hpp)
 __device__ __forceinline__ float ab_secs(unsigned long long ns) {
     return (float)(ns / 1000000000ull) + (float)(ns % 1000000000ull) / 1000000000.0f;
@@ -70,26 +83,26 @@ __device__ __forceinline__ void ab_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ float ab_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 }  // namespace
 
-template <int NK>
-__global__ __launch_bounds__(256) void analysis_batch_preprocess(AbArgs a) {
+// LDS of one wave: two frame rows with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into
+// them), a per-bin row of amplitude weights, the frame's continuous peaks and their accuracy / deviation (npad / 2 each), flags,
+// the compacted list of flagged bins, the peak routines' scratch and the lean routine's peak list
+__host__ __device__ inline unsigned ab_wave_bytes(int n_bins, unsigned scratch_bytes) {
+    const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
+    return (unsigned)((sizeof(float) * (2 * (npad + 2 * PK_PAD) + npad + 4 * (npad / 2)) + npad /*flags*/ + 2 * npad /*flagged bins: npad u16*/ +
+                       scratch_bytes + npad /*lean peak list: npad / 2 u16*/ + 15) / 16 * 16);
+}
+
+template <int NK, bool DIST, int OCC>   // OCC: waves per SIMD the register budget is cut for (4 waves per workgroup: OCC workgroups per CU)
+__global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x * 4 + wave;
-    if (s >= a.n_streams) return;   // (no workgroup barrier below: waves are independent)
     const int n = a.n_bins, npad = (n + 63) / 64 * 64, words = (n + 31) / 32;
-    unsigned char* base = ab_lds + (size_t)wave * a.wave_bytes;
-    float* rowA = reinterpret_cast<float*>(base);               // the smoothed frame (find_peaks input), later pitch_accuracy
-    float* rowB = rowA + npad;                                   // the raw frame, later pitch_deviation
-    float* cw = rowB + npad;                                     // per-bin / per-peak terms of the sequential sums
-    float* cs = cw + npad;
-    float* pc_c = cs + npad;                                     // peaks_continuous of the frame: center, size (npad / 2 each)
-    float* pc_s = pc_c + npad / 2;
-    unsigned char* flag = reinterpret_cast<unsigned char*>(pc_s + npad / 2);   // is-peak / around-a-raw-peak flags
-    unsigned char* scratch = flag + npad;                        // peaks_wave_nk's scratch
-    const uint16_t* plist = reinterpret_cast<const uint16_t*>(scratch + npad);
+    const float INF = __builtin_huge_valf();
 
     PeakParamsDev ps{};   // analysis.rs:332-349: bass config at or below highest_bassnote, general config above
     ps.n_bins = n; ps.bpo = a.bpo; ps.min_freq = a.min_freq; ps.lnf = a.lnf;
@@ -97,14 +110,62 @@ __global__ __launch_bounds__(256) void analysis_batch_preprocess(AbArgs a) {
     ps.bass_min_prominence = a.bass_prom; ps.bass_min_height = a.bass_h;
     ps.highest_bassnote = a.highest_bassnote; ps.harmonic_threshold = a.harm_thr;
     ps.dist = a.dist; ps.min_bin = a.min_bin;
-    ps.mask = a.o.peak_mask ? a.o.peak_mask + (size_t)s * a.n_frames * words : nullptr;
-    ps.count = a.o.peak_count ? a.o.peak_count + (size_t)s * a.n_frames : nullptr;
+    ps.mask = (a.o.peak_mask && s < a.n_streams) ? a.o.peak_mask + (size_t)s * a.n_frames * words : nullptr;
+    ps.count = (a.o.peak_count && s < a.n_streams) ? a.o.peak_count + (size_t)s * a.n_frames : nullptr;
     ps.center = nullptr; ps.size = nullptr; ps.max_peaks = 0;
     PeakParamsDev pg = ps;   // calmness.rs:40: the general config on the whole raw frame
     pg.bass_min_prominence = a.peak_prom; pg.bass_min_height = a.peak_h;
     pg.mask = nullptr; pg.count = nullptr;
 
+    // workgroup-shared: the per-bin thresholds of the lean routine's candidate test, for the two configurations
+    float* thr = reinterpret_cast<float*>(ab_lds);   // [4][npad]: H, P of the split configuration, H, P of the general one
+    peaks_lean_thresholds(thr, thr + npad, ps, tid, 256);
+    peaks_lean_thresholds(thr + 2 * npad, thr + 3 * npad, pg, tid, 256);
+    __syncthreads();
+    if (s >= a.n_streams) return;   // (no workgroup barrier below: waves are independent)
+
+    unsigned char* base = ab_lds + (size_t)4 * npad * sizeof(float) + (size_t)wave * a.wave_bytes;
+    float* rowA = reinterpret_cast<float*>(base) + PK_PAD;      // the smoothed frame (find_peaks input), +INF on both sides
+    float* rowB = rowA + npad + 2 * PK_PAD;                     // the raw frame
+    float* pw = rowB + npad + PK_PAD;                           // 10^(dB / 10) of the bins around a raw peak
+    float* pc_c = pw + npad;                                    // peaks_continuous of the frame: center, size (npad / 2 each)
+    float* pc_s = pc_c + npad / 2;
+    float* pk_acc = pc_s + npad / 2;                            // ... and their pitch accuracy / deviation
+    float* pk_dev = pk_acc + npad / 2;
+    unsigned char* flag = reinterpret_cast<unsigned char*>(pk_dev + npad / 2);   // is-peak / around-a-raw-peak flags
+    uint16_t* flist = reinterpret_cast<uint16_t*>(flag + npad);                  // compacted lists: bass peaks, then flagged bins (room for npad)
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(flist + npad);     // the peak routines' scratch
+    uint16_t* plist_lean = reinterpret_cast<uint16_t*>(scratch + a.scratch_bytes);
+    const uint16_t* plist_gen = reinterpret_cast<const uint16_t*>(scratch + npad);   // where peaks_wave_nk leaves its list
+    for (int i = lane; i < PK_PAD; i += 64) {   // sentinels of both rows (the frame's own tail up to npad follows below, once)
+        rowA[-PK_PAD + i] = INF; rowB[-PK_PAD + i] = INF;
+        rowA[npad + i] = INF; rowB[npad + i] = INF;
+    }
+    for (int i = n + lane; i < npad; i += 64) {
+        rowA[i] = INF; rowB[i] = INF;
+    }
+
+    // find_peaks of one frame row: the lean routine, or — a plateau of three or more samples somewhere in the frame, or the
+    // developer switch — the generic one; returns where the peak list (ascending bins, u16) was left
+    auto find_peaks_row = [&](float* row, const float* tH, const float* tP, const PeakParamsDev& pp, int f, uint32_t& total) -> const uint16_t* {
+        uint32_t n_cand[1] = {0}, np[1] = {0};
+        bool done = false;
+        if (!a.generic_peaks) done = peaks_lean_scan<NK, DIST>(row, scratch, tH, tP, n_cand[0], pp, lane);
+        if (done) {
+            const bool wr[1] = {true};
+            const size_t fr_[1] = {(size_t)f};
+            peaks_lean_walk<NK, 1>(row, 0, scratch, 0, plist_lean, npad / 2, n_cand, np, wr, fr_, pp, lane);
+            total = np[0];
+            return plist_lean;
+        }
+        ab_wave_sync();
+        peaks_wave_nk<NK>(row, scratch, (size_t)f, pp, lane, &total);
+        return plist_gen;
+    };
+
     float y_sm[NK], y_calm[NK], y_rel[NK], y_glow[NK];
+    float bm[NK], glow_k[NK];   // analysis.rs:310-316 base * frequency_multiplier; afterglow.rs:31 decay per bin
+    const float bpo_f = (float)a.bpo, n_f = (float)n;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int bin = lane + 64 * k;
@@ -113,56 +174,64 @@ __global__ __launch_bounds__(256) void analysis_batch_preprocess(AbArgs a) {
         y_calm[k] = in ? a.calm[(size_t)s * n + bin] : 0.0f;
         y_rel[k] = in ? a.released[(size_t)s * n + bin] : 0.0f;
         y_glow[k] = in ? a.afterglow[(size_t)s * n + bin] : 0.0f;
+        const float octave_fraction = (float)bin / bpo_f / (float)a.octaves;
+        const float frequency_multiplier = 1.5f - 0.5f * octave_fraction;
+        bm[k] = (float)a.base_ms * frequency_multiplier;
+        glow_k[k] = 0.85f - 0.15f * ((float)bin / n_f);
     }
     float scene = a.scene[s], tuning = a.tuning[s];
-    const float bpo_f = (float)a.bpo, n_f = (float)n;
     const float note_s = ab_secs(a.note_ns), scene_s = ab_secs(a.scene_ns), tuning_s = ab_secs(a.tuning_ns);
-    float pf_last[NK], acc_last[NK], dev_last[NK];
+    const bool last_call_frame_state = true;   // peak-filtered frame, pitch accuracy / deviation of the call's LAST frame are part of the state (the getters)
+    const float* db_s = a.db + (size_t)s * a.n_frames * n;
+    float xn[NK];   // the next frame's values, fetched a frame ahead
 #pragma unroll
-    for (int k = 0; k < NK; ++k) pf_last[k] = acc_last[k] = dev_last[k] = 0.0f;
+    for (int k = 0; k < NK; ++k) xn[k] = (lane + 64 * k < n && a.n_frames > 0) ? db_s[lane + 64 * k] : 0.0f;
 
     for (int f = 0; f < a.n_frames; ++f) {
         const size_t fr = (size_t)s * a.n_frames + f;
         const unsigned long long dt_ns = a.frame_times ? a.frame_times[f] : a.frame_ns;
         const float dt_s = ab_secs(dt_ns);
+        const float* tab = a.alpha_tab ? a.alpha_tab + (size_t)(a.frame_row ? a.frame_row[f] : 0u) * a.tab_stride : nullptr;
+        const float alpha_c = tab ? tab[0] : 1.0f - ab_exp(-2.0f * dt_s / note_s);
+        const float alpha_s = tab ? tab[1] : 1.0f - ab_exp(-2.0f * dt_s / scene_s);
+        const float alpha_t = tab ? tab[2] : 1.0f - ab_exp(-2.0f * dt_s / tuning_s);
         // ---- analysis.rs:295-323: per-bin EMA with a frequency- and calmness-dependent horizon
         const float cm = a.calm_min + (a.calm_max - a.calm_min) * scene;
         float xr[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
+            xr[k] = xn[k];
             if (bin < n) {
-                const float x = a.db[fr * n + bin];
-                xr[k] = x;
+                const float x = xr[k];
+                if (f + 1 < a.n_frames) xn[k] = db_s[(size_t)(f + 1) * n + bin];
                 if (!a.smooth_has) {
                     y_sm[k] = x;   // util.rs:117-120
                 } else {
-                    unsigned long long hms = 0;
-                    if (a.base_ms > 0) {
-                        const float octave_fraction = (float)bin / bpo_f / (float)a.octaves;
-                        const float frequency_multiplier = 1.5f - 0.5f * octave_fraction;
-                        hms = ab_trunc_u64((float)a.base_ms * frequency_multiplier * cm);
-                    }
-                    const float alpha = 1.0f - ab_exp(-2.0f * dt_s / ab_secs(hms * 1000000ull));
+                    const unsigned long long hms = a.base_ms > 0 ? ab_trunc_u64(bm[k] * cm) : 0ull;
+                    float alpha;
+                    if (tab && hms < (unsigned long long)a.tab_n) alpha = tab[4 + (int)hms];
+                    else alpha = 1.0f - ab_exp(-2.0f * dt_s / ab_secs(hms * 1000000ull));
                     y_sm[k] = y_sm[k] + alpha * (x - y_sm[k]);
                 }
                 rowA[bin] = y_sm[k];
                 rowB[bin] = x;
-            } else {
-                xr[k] = 0.0f;
             }
         }
         ab_wave_sync();
         // ---- analysis.rs:332-349: peaks of the smoothed frame (mask / count go straight to the outputs)
         uint32_t total = 0;
-        peaks_wave_nk<NK>(rowA, scratch, (size_t)f, ps, lane, &total);
+        const uint16_t* plist = find_peaks_row(rowA, thr, thr + npad, ps, f, total);
         ab_wave_sync();
-        // ---- peak_detection.rs:61-148, :172-241: one lane per peak (ascending bins = ascending centres: a centre stays
-        //      between its peak's neighbours and peaks are never adjacent)
+        // ---- peak_detection.rs:61-148: one lane per peak (ascending bins = ascending centres: a centre stays between its peak's
+        //      neighbours and peaks are never adjacent)
         for (int k = 0; k < NK; ++k)
             if (lane + 64 * k < npad) flag[lane + 64 * k] = 0;
-        for (uint32_t idx = lane; idx < total; idx += 64) {
-            const int p = plist[idx];
+        uint32_t n_bass = 0;
+        for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+            const uint32_t idx = i0 + lane;
+            const bool have = idx < total;
+            const int p = have ? plist[idx] : 1;
             float ctr, sz;
             if (p < 1 || p > n - 2) {
                 ctr = (float)p;
@@ -188,98 +257,146 @@ __global__ __launch_bounds__(256) void analysis_batch_preprocess(AbArgs a) {
                     sz = fmaxf(rowA[lower] * (1.0f - fract) + rowA[upper] * fract, 0.0f);
                 }
             }
-            if (!(ctr > (float)a.highest_bassnote)) {   // promote_bass_peaks_with_harmonics
-                const float f0 = a.min_freq * ab_pow(2.0f, ctr / bpo_f);
-                const float p0 = ab_pow(10.0f, sz / 10.0f);
-                float score = 0.0f;
-                const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
-#pragma unroll
-                for (int h = 2; h <= 5; ++h) {
-                    const float hf = f0 * (float)h;
-                    if (hf >= a.min_freq) {
-                        const float hb = (ab_log2(hf) - ab_log2(a.min_freq)) * bpo_f;
-                        if (hb >= 0.0f && hb < n_f) {
-                            const int lo = (int)floorf(hb);
-                            const int hi = min((int)ceilf(hb), n - 1);
-                            const float frac = hb - truncf(hb);
-                            const float adb = (lo == hi) ? rowA[lo] : (rowA[lo] * (1.0f - frac) + rowA[hi] * frac);
-                            const float hp = ab_pow(10.0f, adb / 10.0f);
-                            if (hp > p0 * a.harm_thr) score += hp * wts[h - 2];
-                        }
-                    }
-                }
-                if (score > 0.0f) {
-                    const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
-                    sz += 10.0f * ab_log10(boost);
+            if (have) {
+                pc_c[idx] = ctr;
+                pc_s[idx] = sz;
+                flag[p] = 1;
+            }
+            // promote_bass_peaks_with_harmonics applies to the peaks whose centre is not above highest_bassnote: their list
+            // positions go to the head of flist (free until the calmness step)
+            const bool is_bass = have && !(ctr > (float)a.highest_bassnote);
+            const unsigned long long bmk = __ballot(is_bass);
+            if (is_bass) flist[n_bass + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+            n_bass += __popcll(bmk);
+        }
+        ab_wave_sync();
+        // ---- peak_detection.rs:172-241: FOUR lanes per bass peak, one per harmonic h = 2 .. 5 (their log2 / powf evaluations run
+        //      side by side); the score is then added up in the reference's order h = 2, 3, 4, 5 by every lane of the quad
+        for (uint32_t q0 = 0; q0 < n_bass; q0 += 16) {
+            const uint32_t q = q0 + (lane >> 2);
+            const bool have = q < n_bass;
+            const uint32_t idx = have ? flist[q] : 0;
+            const int h = 2 + (lane & 3);
+            const float ctr = pc_c[idx];
+            float sz = pc_s[idx];
+            const float f0 = a.min_freq * ab_exp2(ctr / bpo_f);
+            const float p0 = ab_pow10(sz / 10.0f);
+            const float wts[4] = {0.5f, 0.3f, 0.15f, 0.05f};
+            float term = 0.0f;   // this harmonic's contribution (+0.0: adding it changes nothing, as not adding it)
+            const float hf = f0 * (float)h;
+            if (have && hf >= a.min_freq) {
+                const float hb = (ab_log2(hf) - a.log2_min_freq) * bpo_f;
+                if (hb >= 0.0f && hb < n_f) {
+                    const int lo = (int)floorf(hb);
+                    const int hi = min((int)ceilf(hb), n - 1);
+                    const float frac = hb - truncf(hb);
+                    const float adb = (lo == hi) ? rowA[lo] : (rowA[lo] * (1.0f - frac) + rowA[hi] * frac);
+                    const float hp = ab_pow10(adb / 10.0f);
+                    if (hp > p0 * a.harm_thr) term = hp * wts[h - 2];
                 }
             }
-            pc_c[idx] = ctr;
-            pc_s[idx] = sz;
-            flag[p] = 1;
-            if (a.o.center && idx < a.o.max_peaks) {
-                a.o.center[fr * a.o.max_peaks + idx] = ctr;
-                a.o.size[fr * a.o.max_peaks + idx] = sz;
+            float score = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) score += __shfl(term, (lane & ~3) + j);
+            if (have && (lane & 3) == 0 && score > 0.0f) {
+                const float boost = fminf(1.0f + 0.5f * (score / fmaxf(p0, 1e-6f)), 1.5f);
+                sz += 10.0f * ab_log10(boost);
+                pc_s[idx] = sz;
             }
         }
         ab_wave_sync();
+        if (a.o.center) {
+            for (uint32_t idx = lane; idx < total && idx < a.o.max_peaks; idx += 64) {
+                a.o.center[fr * a.o.max_peaks + idx] = pc_c[idx];
+                a.o.size[fr * a.o.max_peaks + idx] = pc_s[idx];
+            }
+        }
         // ---- afterglow.rs:27-36, :10-21
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
             if (bin < n) {
-                pf_last[k] = flag[bin] ? y_sm[k] : 0.0f;
+                const float pf = flag[bin] ? y_sm[k] : 0.0f;
                 float g = y_glow[k];
-                g *= 0.85f - 0.15f * ((float)bin / n_f);
+                g *= glow_k[k];
                 if (g < y_sm[k]) g = y_sm[k];
                 y_glow[k] = g;
                 if (a.o.x_vqt_smoothed) a.o.x_vqt_smoothed[fr * n + bin] = y_sm[k];
-                if (a.o.x_vqt_peakfiltered) a.o.x_vqt_peakfiltered[fr * n + bin] = pf_last[k];
+                if (a.o.x_vqt_peakfiltered) a.o.x_vqt_peakfiltered[fr * n + bin] = pf;
                 if (a.o.x_vqt_afterglow) a.o.x_vqt_afterglow[fr * n + bin] = g;
+                if (last_call_frame_state && f == a.n_frames - 1) a.peakfiltered[(size_t)s * n + bin] = pf;
             }
         }
-        // ---- pitch_analysis.rs:55-66: tuning-grid inaccuracy, power-weighted, accumulated in peak order
-        for (uint32_t idx = lane; idx < total; idx += 64) {
-            const float power = ab_pow(10.0f, pc_s[idx] / 10.0f);
-            const float semis = pc_c[idx] * 12.0f / bpo_f;
-            cw[idx] = fabsf(semis - roundf(semis)) * power;
-            cs[idx] = power;
-        }
-        ab_wave_sync();
+        // ---- pitch_analysis.rs:55-66: tuning-grid inaccuracy, power-weighted, accumulated in peak order;
+        //      pitch_analysis.rs:12-42: per-bin accuracy / deviation at the peaks' nearest bins, later peaks overwrite earlier ones
+        //      (centres ascend, so the peaks that round to one bin are neighbours in the list: the last of them writes)
         {
             float inaccuracy_sum = 0.0f, power_sum = 0.0f;
-            for (uint32_t idx = 0; idx < total; ++idx) {   // (every lane runs the same sequence on broadcast reads: a uniform result)
-                power_sum += cs[idx];
-                inaccuracy_sum += cw[idx];
+            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                const uint32_t idx = i0 + lane;
+                const bool have = idx < total;
+                const float c = have ? pc_c[idx] : 0.0f;
+                const float power = have ? ab_pow10(pc_s[idx] / 10.0f) : 0.0f;
+                const float semis = c * 12.0f / bpo_f;
+                const float deviation = semis - roundf(semis);
+                const float wi = fabsf(deviation) * power;
+                const uint32_t cnt = min(64u, total - i0);
+                for (uint32_t j = 0; j < cnt; ++j) {   // (uniform: every lane adds the same values in list order)
+                    power_sum += ab_readlane(power, (int)j);
+                    inaccuracy_sum += ab_readlane(wi, (int)j);
+                }
+                if (have) {   // (the per-bin rows are put together after the calmness step, in the raw frame's row)
+                    pk_acc[idx] = fmaxf(1.0f - 2.0f * fabsf(deviation), 0.0f);
+                    pk_dev[idx] = deviation;
+                }
             }
             const float avg = power_sum > 0.0f ? inaccuracy_sum / power_sum : 0.0f;
-            const float alpha_t = 1.0f - ab_exp(-2.0f * dt_s / tuning_s);
             tuning = tuning + alpha_t * (100.0f * avg - tuning);
         }
         ab_wave_sync();
         // ---- calmness.rs:23-95: peaks of the RAW frame mark the bins "around a note"
         uint32_t total_raw = 0;
-        peaks_wave_nk<NK>(rowB, scratch, (size_t)f, pg, lane, &total_raw);
+        const uint16_t* plist_raw = find_peaks_row(rowB, thr + 2 * npad, thr + 3 * npad, pg, f, total_raw);
         ab_wave_sync();
         for (int k = 0; k < NK; ++k)
             if (lane + 64 * k < npad) flag[lane + 64 * k] = 0;
         ab_wave_sync();
         for (uint32_t idx = lane; idx < total_raw; idx += 64) {
-            const int p = plist[idx];
+            const int p = plist_raw[idx];
             const int lo = max(0, p - a.radius), hi = min(n, p + a.radius);
             for (int i = lo; i < hi; ++i) flag[i] = 1;
         }
         ab_wave_sync();
+        // amplitude weights 10^(dB / 10) of the flagged bins only (a handful per frame): compacted, one lane per flagged bin
+        bool fl[NK];
         {
-            const float alpha_c = 1.0f - ab_exp(-2.0f * dt_s / note_s);
+            uint32_t n_fl = 0;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int bin = lane + 64 * k;
+                fl[k] = bin < n && flag[bin] != 0;
+                const unsigned long long bmk = __ballot(fl[k]);
+                if (fl[k]) flist[n_fl + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)bin;
+                n_fl += __popcll(bmk);
+            }
+            ab_wave_sync();
+            for (uint32_t idx = lane; idx < n_fl; idx += 64) {
+                const int bin = flist[idx];
+                pw[bin] = ab_pow10(rowA[bin] / 10.0f);
+            }
+            ab_wave_sync();
+        }
+        {
+            float weighted_sum = 0.0f, weight_sum = 0.0f;   // in bin order, as the reference's loop; bins that contribute nothing are skipped
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int bin = lane + 64 * k;
+                float ws = 0.0f, w = 0.0f;
                 if (bin < n) {
-                    float ws = 0.0f, w = 0.0f;
-                    if (flag[bin]) {
+                    if (fl[k]) {
                         y_calm[k] = y_calm[k] + alpha_c * (1.0f - y_calm[k]);
                         y_rel[k] = y_calm[k];
-                        const float power = ab_pow(10.0f, y_sm[k] / 10.0f);
+                        const float power = pw[bin];
                         ws = y_calm[k] * power;
                         w = power;
                     } else {
@@ -290,53 +407,43 @@ __global__ __launch_bounds__(256) void analysis_batch_preprocess(AbArgs a) {
                             ws = y_rel[k] * w;
                         }
                     }
-                    cw[bin] = ws;
-                    cs[bin] = w;
                     if (a.o.calmness) a.o.calmness[fr * n + bin] = y_calm[k];
                 }
-            }
-        }
-        ab_wave_sync();
-        {
-            float weighted_sum = 0.0f, weight_sum = 0.0f;   // in bin order, as the reference's loop (adding a skipped bin's 0 changes nothing)
-            for (int bin = 0; bin < n; ++bin) {
-                weighted_sum += cw[bin];
-                weight_sum += cs[bin];
-            }
-            if (weight_sum > 0.0f) {
-                const float alpha_s = 1.0f - ab_exp(-2.0f * dt_s / scene_s);
-                scene = scene + alpha_s * (weighted_sum / weight_sum - scene);
-            }
-        }
-        ab_wave_sync();
-        // ---- pitch_analysis.rs:12-42: per-bin accuracy / deviation at the peaks' nearest bins, later peaks overwrite earlier ones
-        for (int k = 0; k < NK; ++k)
-            if (lane + 64 * k < npad) {
-                rowA[lane + 64 * k] = 0.0f;
-                rowB[lane + 64 * k] = 0.0f;
-            }
-        ab_wave_sync();
-        if (lane == 0) {
-            for (uint32_t idx = 0; idx < total; ++idx) {
-                const float semis = pc_c[idx] * 12.0f / bpo_f;
-                const float deviation = semis - roundf(semis);
-                const float accuracy = fmaxf(1.0f - 2.0f * fabsf(deviation), 0.0f);
-                const float rc = roundf(pc_c[idx]);
-                if (rc >= 0.0f && rc < n_f) {
-                    rowA[(int)rc] = accuracy;
-                    rowB[(int)rc] = deviation;
+                unsigned long long m = __ballot(ws != 0.0f || w != 0.0f);   // (adding +0.0 to a non-negative sum changes nothing)
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    weighted_sum += ab_readlane(ws, b);
+                    weight_sum += ab_readlane(w, b);
                 }
             }
+            if (weight_sum > 0.0f) scene = scene + alpha_s * (weighted_sum / weight_sum - scene);
+        }
+        // ---- pitch accuracy / deviation rows, in the raw frame's row (dead now): bin <- 1 + index of the peak that writes it
+        ab_wave_sync();
+        for (int k = 0; k < NK; ++k) {
+            const int bin = lane + 64 * k;
+            if (bin < n) rowB[bin] = 0.0f;
+        }
+        ab_wave_sync();
+        for (uint32_t idx = lane; idx < total; idx += 64) {
+            const float rc = roundf(pc_c[idx]);
+            const bool last = idx + 1 >= total || roundf(pc_c[idx + 1]) != rc;
+            if (last && rc >= 0.0f && rc < n_f) rowB[(int)rc] = (float)(idx + 1);
         }
         ab_wave_sync();
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
             if (bin < n) {
-                acc_last[k] = rowA[bin];
-                dev_last[k] = rowB[bin];
-                if (a.o.pitch_accuracy) a.o.pitch_accuracy[fr * n + bin] = acc_last[k];
-                if (a.o.pitch_deviation) a.o.pitch_deviation[fr * n + bin] = dev_last[k];
+                const int w = (int)rowB[bin];
+                const float acc = w ? pk_acc[w - 1] : 0.0f, dev = w ? pk_dev[w - 1] : 0.0f;
+                if (a.o.pitch_accuracy) a.o.pitch_accuracy[fr * n + bin] = acc;
+                if (a.o.pitch_deviation) a.o.pitch_deviation[fr * n + bin] = dev;
+                if (last_call_frame_state && f == a.n_frames - 1) {
+                    a.pitch_acc[(size_t)s * n + bin] = acc;
+                    a.pitch_dev[(size_t)s * n + bin] = dev;
+                }
             }
         }
         if (lane == 0) {
@@ -353,11 +460,6 @@ __global__ __launch_bounds__(256) void analysis_batch_preprocess(AbArgs a) {
             a.calm[(size_t)s * n + bin] = y_calm[k];
             a.released[(size_t)s * n + bin] = y_rel[k];
             a.afterglow[(size_t)s * n + bin] = y_glow[k];
-            if (a.n_frames > 0) {
-                a.peakfiltered[(size_t)s * n + bin] = pf_last[k];
-                a.pitch_acc[(size_t)s * n + bin] = acc_last[k];
-                a.pitch_dev[(size_t)s * n + bin] = dev_last[k];
-            }
         }
     }
     if (lane == 0) {
@@ -374,6 +476,7 @@ AnalysisBatch::~AnalysisBatch() {
     for (float* p : {d_smoothed_, d_calm_, d_released_, d_afterglow_, d_peakfiltered_, d_pitch_acc_, d_pitch_dev_, d_scene_, d_tuning_, d_lnf_})
         if (p) (void)hipFree(p);
     if (d_times_) (void)hipFree(d_times_);
+    if (d_tab_) (void)hipFree(d_tab_);
 }
 
 pvq_status AnalysisBatch::create(int device_id, const VqtRange& range, const FullAnalysisParameters& params, uint32_t n_streams,
@@ -472,7 +575,70 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
         PVQ_HIP(hipMemcpyAsync(d_times_, frame_times_ns, n_frames * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
         a.frame_times = d_times_;
     }
+    // EMA weights from the host's libm (util.rs:106-110: alpha = 1 - exp(-2 timestep / time_horizon), all f32).  The per-bin
+    // horizons of analysis.rs:301-323 are whole milliseconds between 0 and base * 1.5 * max(calmness multiplier): one table row per
+    // distinct frame time of the call covers every bin of every frame, built with the very expf the host AnalysisState calls — the
+    // device's own evaluation (a double exp rounded once) differs from it by an ulp now and then.
+    a.alpha_tab = nullptr;
+    a.frame_row = nullptr;
+    a.tab_n = a.tab_stride = 0;
+    {
+        const float cmax = std::max(std::max(a.calm_min, a.calm_max), 0.0f);
+        const double hmax_d = (double)a.base_ms * 1.5 * (double)cmax + 2.0;
+        const size_t tab_n = smooth_has_ && hmax_d < 65536.0 ? (size_t)hmax_d + 1 : 1;
+        std::vector<uint64_t> distinct;
+        std::vector<uint32_t> rows;
+        if (frame_times_ns) {
+            rows.resize(n_frames);
+            std::unordered_map<uint64_t, uint32_t> seen;
+            for (size_t f = 0; f < n_frames; ++f) {
+                auto it = seen.find(frame_times_ns[f]);
+                if (it == seen.end()) {
+                    it = seen.emplace(frame_times_ns[f], (uint32_t)distinct.size()).first;
+                    distinct.push_back(frame_times_ns[f]);
+                }
+                rows[f] = it->second;
+            }
+        } else {
+            distinct.push_back(frame_time.ns);
+        }
+        const size_t stride = 4 + tab_n;
+        if (distinct.size() * stride <= ((size_t)1 << 22)) {   // at most 16 MB of weights; beyond that the kernel evaluates them itself
+            std::vector<float> tab(distinct.size() * stride);
+            for (size_t r = 0; r < distinct.size(); ++r) {
+                const Duration ts{distinct[r]};
+                float* row = tab.data() + r * stride;
+                auto alpha = [&](Duration horizon) { return ema_alpha(ts, horizon); };   // (analysis_host.cpp: what EmaMeasurement::update_with_timestep calls)
+                row[0] = alpha(params_.note_calmness_smoothing_duration);
+                row[1] = alpha(params_.scene_calmness_smoothing_duration);
+                row[2] = alpha(params_.tuning_inaccuracy_smoothing_duration);
+                row[3] = 0.0f;
+                for (size_t h = 0; h < tab_n; ++h) row[4 + h] = alpha(Duration::from_millis(h));
+            }
+            const size_t need = tab.size() * sizeof(float) + rows.size() * sizeof(uint32_t);
+            if (tab_cap_ < need) {
+                if (d_tab_) PVQ_HIP(hipFree(d_tab_));
+                d_tab_ = nullptr;
+                tab_cap_ = 0;
+                PVQ_HIP(hipStreamSynchronize(stream));
+                PVQ_HIP(hipMalloc(&d_tab_, need));
+                tab_cap_ = need;
+            }
+            // (synchronous copies from pageable host memory: the vectors may go out of scope when this returns)
+            PVQ_HIP(hipStreamSynchronize(stream));   // an earlier call on this stream may still read the table
+            PVQ_HIP(hipMemcpy(d_tab_, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+            a.alpha_tab = static_cast<const float*>(d_tab_);
+            a.tab_n = (int)tab_n;
+            a.tab_stride = (int)stride;
+            if (!rows.empty()) {
+                uint32_t* d_rows = reinterpret_cast<uint32_t*>(static_cast<char*>(d_tab_) + tab.size() * sizeof(float));
+                PVQ_HIP(hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                a.frame_row = d_rows;
+            }
+        }
+    }
     a.lnf = d_lnf_;
+    a.log2_min_freq = std::log2(range_.min_freq);
     {   // peak_detection.rs:37, :45 and calmness.rs:37, as the batched peak kernels derive them
         const float dist_f = std::round((float)a.bpo * 0.4f / 12.0f);
         a.dist = dist_f > 0.0f ? (int)dist_f : 0;
@@ -484,19 +650,33 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     a.scene = d_scene_; a.tuning = d_tuning_;
     a.o = outs;
     const int npad = (a.n_bins + 63) / 64 * 64;
-    a.scratch_bytes = (unsigned)peaks_scratch_bytes(a.n_bins, a.dist);
-    a.wave_bytes = (unsigned)(sizeof(float) * (4 * npad + npad) + npad + a.scratch_bytes + 15) / 16 * 16;
+    a.scratch_bytes = (unsigned)((std::max(peaks_scratch_bytes(a.n_bins, a.dist), peaks_lean_scratch_bytes(a.n_bins, a.dist)) + 15) / 16 * 16);
+    a.wave_bytes = ab_wave_bytes(a.n_bins, a.scratch_bytes);
+    a.generic_peaks = dev_knob("PVQ_AB_GENERIC", 0);
     const dim3 grid((n_streams_ + 3) / 4);
-    const size_t lds = (size_t)a.wave_bytes * 4;
-    if (a.n_bins <= 256)
-        hipLaunchKernelGGL(analysis_batch_preprocess<4>, grid, dim3(256), lds, stream, a);
-    else if (a.n_bins <= 512) {
-        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(analysis_batch_preprocess<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(analysis_batch_preprocess<8>, grid, dim3(256), lds, stream, a);
-    } else {
-        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(analysis_batch_preprocess<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(analysis_batch_preprocess<16>, grid, dim3(256), lds, stream, a);
-    }
+    const size_t lds = (size_t)4 * npad * sizeof(float) + (size_t)a.wave_bytes * 4;
+    auto launch = [&](auto kern) -> pvq_status {
+        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+        return PVQ_OK;
+    };
+    pvq_status lst;
+    const bool dist = a.dist > 1;
+    const int occ = dev_knob("PVQ_AB_OCC", 2);   // (developer build: A/B of the register budget)
+#ifdef PVQ_DEV_KNOBS
+#define PVQ_AB_LAUNCH(NK) \
+    (occ == 4 ? (dist ? launch(analysis_batch_preprocess<NK, true, 4>) : launch(analysis_batch_preprocess<NK, false, 4>)) \
+     : occ == 3 ? (dist ? launch(analysis_batch_preprocess<NK, true, 3>) : launch(analysis_batch_preprocess<NK, false, 3>)) \
+                : (dist ? launch(analysis_batch_preprocess<NK, true, 2>) : launch(analysis_batch_preprocess<NK, false, 2>)))
+#else
+#define PVQ_AB_LAUNCH(NK) (dist ? launch(analysis_batch_preprocess<NK, true, 2>) : launch(analysis_batch_preprocess<NK, false, 2>))
+    (void)occ;
+#endif
+    if (a.n_bins <= 256) lst = PVQ_AB_LAUNCH(4);
+    else if (a.n_bins <= 512) lst = PVQ_AB_LAUNCH(8);
+    else lst = PVQ_AB_LAUNCH(16);
+#undef PVQ_AB_LAUNCH
+    if (lst != PVQ_OK) return lst;
     PVQ_HIP(hipGetLastError());
     return PVQ_OK;
 }

@@ -69,6 +69,8 @@ class AnalysisBatch {
     float* d_lnf_ = nullptr;           // ln(f_k), host libm (peak_detection.rs:81-86)
     unsigned long long* d_times_ = nullptr;   // per-frame times of the running call
     size_t times_cap_ = 0;
+    void* d_tab_ = nullptr;            // EMA weights of the running call (host libm), then the frames' row indices
+    size_t tab_cap_ = 0;
 };
 
 }  // namespace pvq

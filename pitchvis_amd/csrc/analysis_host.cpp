@@ -21,10 +21,16 @@ uint64_t trunc_sat_u64(float x) {
 float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 }  // namespace
 
+// util.rs:108: the EMA weight.  One definition for the host AnalysisState and for the weight tables the batched GPU form is
+// handed (analysis_batch.hip): both get this translation unit's expf (g++, no fast-math, no FMA contraction).
+float ema_alpha(Duration timestep, Duration horizon) {
+    return 1.0f - std::exp(-2.0f * timestep.as_secs_f32() / horizon.as_secs_f32());
+}
+
 // util.rs:106-121
 void EmaMeasurement::update_with_timestep(float new_value, Duration timestep) {
     if (has_) {
-        const float alpha = 1.0f - std::exp(-2.0f * timestep.as_secs_f32() / horizon_.as_secs_f32());
+        const float alpha = ema_alpha(timestep, horizon_);
         update_with_alpha(new_value, alpha);
     } else {
         y_ = new_value;

@@ -27,6 +27,9 @@ struct Duration {
     }
 };
 
+// util.rs:108: alpha = 1 - exp(-2 timestep / time_horizon), in f32 with the host's expf
+float ema_alpha(Duration timestep, Duration horizon);
+
 // util.rs:91-137
 class EmaMeasurement {
    public:
