@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVQ_ABI_VERSION 3   /* 3: + pvq_vqt_set_workspace_limit, pvq_plan_shard, pvq_vqt_analyze_batch_multi, pvq_analysis_batch_*, profiling mode 2; per-call NaN flag semantics of the synchronous entry points */
+#define PVQ_ABI_VERSION 4   /* 4: + pvq_vqt_calculate_batch_db_streams, pvq_vqt_analyze_batch_streams (many streams per call).  3: + pvq_vqt_set_workspace_limit, pvq_plan_shard, pvq_vqt_analyze_batch_multi, pvq_analysis_batch_*, profiling mode 2; per-call NaN flag semantics of the synchronous entry points */
 
 /* replaces VqtParameters + VqtRange (vqt.rs:238-262, 278-331), flattened POD */
 typedef struct pvq_vqt_params {
@@ -219,6 +219,28 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt *v, const float *d_pcm, size_t n
                                         uint32_t *d_peak_count, float *d_center, float *d_size,
                                         uint32_t max_peaks, void *stream);
 
+
+/* ---- many streams, one call ----------------------------------------------------------------------------
+ * The reference's batch driver analyses MANY independent files side by side, one Vqt per rayon worker
+ * (pitchvis_train/src/train.rs:146-163), and a stereo recording is two streams.  Here one handle takes all of them in one
+ * call: d_pcm is a HOST array of n_streams device pointers; stream s holds n_lead[s] + n_frames[s] * hop samples (n_lead
+ * NULL: no history anywhere) and is framed exactly as by pvq_vqt_calculate_batch_db_device; its frame f goes to row
+ * s * out_stride_frames + f of d_out_db [n_streams][out_stride_frames][n_bins] (out_stride_frames >= every n_frames[s]) — the
+ * layout pvq_analysis_batch_preprocess_device reads, so PCM -> VQT -> AnalysisState::preprocess of many streams never leaves
+ * the device.  Rows a stream does not fill are zero frames.  With a power-of-two hop (the block-DFT path) every stage covers
+ * ALL streams with one launch — 64 streams of 2 048 frames cost what one 131 072-frame stream costs, not 64 launch ramps and
+ * tails per stage; every value equals, bit for bit, what the single-stream call computes for that stream.  Asynchronous on
+ * `stream`; NaN / Inf policy as for the device-pointer entry points (pvq_vqt_input_status). */
+pvq_status pvq_vqt_calculate_batch_db_streams(pvq_vqt *v, const float *const *d_pcm, const size_t *n_lead,
+                                              const size_t *n_frames, uint32_t n_streams, size_t hop, float *d_out_db,
+                                              size_t out_stride_frames, void *stream);
+/* The same with the per-frame peak pipeline behind it (as pvq_vqt_analyze_batch_device): peak outputs are laid out by the
+ * same rows, [n_streams][out_stride_frames][...]; any may be NULL (center and size go together). */
+pvq_status pvq_vqt_analyze_batch_streams(pvq_vqt *v, const float *const *d_pcm, const size_t *n_lead,
+                                         const size_t *n_frames, uint32_t n_streams, size_t hop,
+                                         const pvq_analysis_params *a, float *d_out_db, size_t out_stride_frames,
+                                         uint32_t *d_peak_mask, uint32_t *d_peak_count, float *d_center, float *d_size,
+                                         uint32_t max_peaks, void *stream);
 
 /* ---- several devices, one stream ---------------------------------------------------------------------
  * The reference's only data-parallel driver hands every rayon worker its own Vqt (pitchvis_train/src/train.rs:146-155:

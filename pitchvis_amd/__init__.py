@@ -316,6 +316,28 @@ class Vqt:
                                                     _ptr(d_out_db), _ptr(d_peak_mask), _ptr(d_peak_count),
                                                     _ptr(d_center), _ptr(d_size), max_peaks, _stream_handle(stream)))
 
+    def batch_streams_device(self, d_pcms, hop: int, n_frames, d_out_db, out_stride_frames: Optional[int] = None, n_leads=None,
+                             d_peak_mask=None, d_peak_count=None, d_center=None, d_size=None, max_peaks: int = 0,
+                             analysis: Optional[AnalysisParameters] = None, stream=None) -> None:
+        """MANY streams in one call (pvq_vqt_calculate_batch_db_streams / pvq_vqt_analyze_batch_streams): d_pcms a sequence of device
+        tensors (or raw pointers), n_frames a sequence; stream s's frame f goes to d_out_db[s, f] ([n_streams][out_stride_frames]
+        [n_bins], the layout AnalysisBatch.preprocess_device reads).  With any peak output given the per-frame peak pipeline runs
+        behind the transform, outputs laid out by the same rows.  Asynchronous on `stream`."""
+        n = len(d_pcms)
+        n_frames = [int(x) for x in n_frames]
+        if len(n_frames) != n:
+            raise ValueError("one frame count per stream")
+        stride = int(out_stride_frames) if out_stride_frames is not None else (max(n_frames) if n else 0)
+        ptrs = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in d_pcms])
+        nf = (C.c_size_t * max(n, 1))(*n_frames)
+        nl = (C.c_size_t * max(n, 1))(*[int(x) for x in n_leads]) if n_leads is not None else None
+        if d_peak_mask is None and d_peak_count is None and d_center is None:
+            _check(self._L.pvq_vqt_calculate_batch_db_streams(self._h, ptrs, nl, nf, n, hop, _ptr(d_out_db), stride, _stream_handle(stream)))
+        else:
+            ap = (analysis or AnalysisParameters())._c()
+            _check(self._L.pvq_vqt_analyze_batch_streams(self._h, ptrs, nl, nf, n, hop, C.byref(ap), _ptr(d_out_db), stride, _ptr(d_peak_mask),
+                                                         _ptr(d_peak_count), _ptr(d_center), _ptr(d_size), max_peaks, _stream_handle(stream)))
+
     @staticmethod
     def analyze_batch_multi(handles, pcm, hop: int, n_frames: int, n_lead: int = 0, analysis: Optional[AnalysisParameters] = None,
                             max_peaks: int = 64, want_peaks: bool = True):

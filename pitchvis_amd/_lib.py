@@ -17,7 +17,7 @@ EXPORTS = [
     "pvq_vqt_n_groups", "pvq_vqt_group_info", "pvq_vqt_group_csr", "pvq_vqt_filter_params",
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
     "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
-    "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_plan_shard", "pvq_vqt_analyze_batch_multi", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
+    "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_calculate_batch_db_streams", "pvq_vqt_analyze_batch_streams", "pvq_plan_shard", "pvq_vqt_analyze_batch_multi", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
     "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_set_workspace_limit", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
     "pvq_analysis_batch_create", "pvq_analysis_batch_destroy", "pvq_analysis_batch_update_vqt_smoothing_duration",
@@ -159,6 +159,12 @@ def load():
     L.pvq_vqt_analyze_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(CAnalysisParams),
                                                vp, vp, vp, vp, vp, C.c_uint32, vp]
     L.pvq_vqt_analyze_batch_device.restype = C.c_int
+    szp = C.POINTER(C.c_size_t)
+    L.pvq_vqt_calculate_batch_db_streams.argtypes = [vp, C.POINTER(vp), szp, szp, C.c_uint32, C.c_size_t, vp, C.c_size_t, vp]
+    L.pvq_vqt_calculate_batch_db_streams.restype = C.c_int
+    L.pvq_vqt_analyze_batch_streams.argtypes = [vp, C.POINTER(vp), szp, szp, C.c_uint32, C.c_size_t, C.POINTER(CAnalysisParams), vp, C.c_size_t,
+                                                vp, vp, vp, vp, C.c_uint32, vp]
+    L.pvq_vqt_analyze_batch_streams.restype = C.c_int
     L.pvq_plan_shard.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(CShard)]; L.pvq_plan_shard.restype = C.c_int
     L.pvq_vqt_analyze_batch_multi.argtypes = [C.POINTER(vp), C.c_uint32, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(CAnalysisParams),
                                               fp, up, up, fp, fp, C.c_uint32]

@@ -407,6 +407,27 @@ pvq_status pvq_vqt_analyze_batch_device(pvq_vqt* v, const float* d_pcm, size_t n
     } catch (...) { return translate_exception(); }
 }
 
+pvq_status pvq_vqt_calculate_batch_db_streams(pvq_vqt* v, const float* const* d_pcm, const size_t* n_lead, const size_t* n_frames,
+                                              uint32_t n_streams, size_t hop, float* d_out_db, size_t out_stride_frames, void* stream) {
+    try {
+        if (!v) return null_handle();
+        return v->impl->batch_streams_device(d_pcm, n_lead, n_frames, n_streams, hop, d_out_db, out_stride_frames, nullptr, nullptr, nullptr,
+                                             nullptr, nullptr, 0, static_cast<hipStream_t>(stream));
+    } catch (...) { return translate_exception(); }
+}
+
+pvq_status pvq_vqt_analyze_batch_streams(pvq_vqt* v, const float* const* d_pcm, const size_t* n_lead, const size_t* n_frames,
+                                         uint32_t n_streams, size_t hop, const pvq_analysis_params* a, float* d_out_db,
+                                         size_t out_stride_frames, uint32_t* d_peak_mask, uint32_t* d_peak_count, float* d_center,
+                                         float* d_size, uint32_t max_peaks, void* stream) {
+    try {
+        if (!v) return null_handle();
+        const pvq::AnalysisParameters ap = to_cpp(a);
+        return v->impl->batch_streams_device(d_pcm, n_lead, n_frames, n_streams, hop, d_out_db, out_stride_frames, &ap, d_peak_mask,
+                                             d_peak_count, d_center, d_size, max_peaks, static_cast<hipStream_t>(stream));
+    } catch (...) { return translate_exception(); }
+}
+
 pvq_status pvq_plan_shard(uint64_t n_frames_total, uint64_t hop, uint64_t window_union, uint32_t rank, uint32_t world, pvq_shard* out) {
     try {
         pvq::ShardPlan sp;

@@ -112,11 +112,22 @@ struct BlockDftTables {
     float2* d_X = nullptr; size_t x_cap = 0;
     float2* d_Y = nullptr; size_t y_cap = 0;   // 64-block partial sums (windows of more than 64 blocks)
     // frame-stripe tile order of the fused kernels, built per (frames, tile rows) and kept for the next launch
+    struct SegKey {   // one run of a launch: what decides its tiles, where its frames go
+        long long pcm_off, base, out_row0;
+        unsigned pcm_bytes;
+        int nf, x_tile0, y_tile0;
+        bool operator==(const SegKey& o) const {
+            return pcm_off == o.pcm_off && base == o.base && out_row0 == o.out_row0 && pcm_bytes == o.pcm_bytes && nf == o.nf && x_tile0 == o.x_tile0 && y_tile0 == o.y_tile0;
+        }
+    };
     struct TileList {
-        int4* d = nullptr; size_t cap = 0;
-        int nf = -1, bm = 0, wide = 0, blocks = 0;
+        int4* d = nullptr; size_t cap = 0;            // device: the list, then the launch's segment table and X-tile map
+        const struct SegDev* d_segs = nullptr;
+        const struct XTile* d_xmap = nullptr;
+        std::vector<SegKey> key;                      // the runs the list was built for (stream geometry included: which tiles may pair up / take 16-byte loads)
+        int bm = 0, wide = 0, blocks = 0;
+        bool multi = false;
         double eff_tiles = 0.0;                       // MFMA work of the list in whole 32-column tiles
-        long long base = 0; unsigned pcm_bytes = 0;   // where the stream starts and ends relative to the tiles: which tiles may pair up (wide entries)
     } tile_lists[4];   // four slots: a batch's first, middle and last sub-batch alternate without rebuilding
     int tile_list_next = 0;
     unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch: 4 slots per sampled tile
@@ -193,6 +204,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // +20 % MFMA work at 48 kHz / hop 256) in exchange for dropping the P round trip through memory
 // (172 MB written + ~200 MB read per 32 768 frames) and the separate combine launch.
 // ------------------------------------------------------------------------------------------------
+// MANY streams in one launch (pvq_vqt_*_streams: the trainer's shape, pitchvis_train/src/train.rs:146-163 — many files side by side).
+// A launch covers a list of SEGMENTS, each a contiguous run of frames of one stream; a tile list entry names its segment
+// (.x bits 16..31), the segment table gives the tile its stream (offset from the launch's base pointer, readable bytes, where
+// frame 0 of the run ends) and the run's first 64-frame tile in X / Y; XTile maps an X tile back to the output rows it holds.
+// segs == nullptr: one segment described by the kernel arguments themselves (the single-stream entry points: unchanged).
+struct alignas(16) SegDev {
+    long long pcm_off;    // samples from GemmTreeArgs::pcm_base to the segment's rebased stream pointer
+    long long base;       // index, relative to that pointer, of the end of the segment's frame 0
+    unsigned pcm_bytes;   // bytes readable from that pointer
+    int n_frames;         // frames of the segment
+    int x_tile0, y_tile0; // its first 64-frame tile in X / in Y
+};
+struct XTile {
+    long long out_row0;   // output row (of out_db, masks, ...) of the tile's frame 0
+    int n_live;           // frames of the tile that exist
+    int y_tile;           // the Y tile that holds the same frames' 64-block partial sums
+};
+
 struct GemmTreeArgs {
     const float* pcm_base;
     unsigned pcm_bytes;
@@ -213,6 +242,7 @@ struct GemmTreeArgs {
     const float4* E16;        // [column tile][k < K / 2][n < 16]: (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}): B operands of the 16x16x4 fp32 form
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
     unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader clock, 100 MHz clock) before and after its K loop
+    const SegDev* segs;           // many-streams launches: the segment table (nullptr: one segment = the arguments above)
 };
 #define PVQ_STAMP(i) \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)stamp_slot * 8 + (i)] = wall_clock64();   // stamp_slot: the tile's (workgroup's) row of the dump
@@ -226,23 +256,52 @@ struct FusedTile {
     int ntl, nt;  // column tile within the group / global
     int f0;       // first frame == first block row
     int nfr;      // rows this group produces: n_frames complete frames, or n_frames + nb - 64 partial sums when nb > 64
+    int xt0, yt0; // first 64-frame tile of the tile's segment in X / Y (0 in a single-stream launch)
 };
+// the stream a tile reads and where its frames go: the kernel arguments, or the tile's entry of the segment table
+struct TileStream {
+    const float* pcm_base;
+    unsigned pcm_bytes;
+    long long base;
+    int n_frames, xt0, yt0;
+};
+__device__ __forceinline__ TileStream tile_stream(const GemmTreeArgs& a, int entry_x) {
+    TileStream ts{a.pcm_base, a.pcm_bytes, a.base, a.n_frames, 0, 0};
+    if (a.segs) {
+        // The entry is the same for every lane, but the compiler cannot know that of loaded data: without the readfirstlanes the
+        // buffer resource built from it counts as lane-dependent and EVERY operand load of the K loop is wrapped in a waterfall loop.
+        const int4* sp = reinterpret_cast<const int4*>(a.segs + ((unsigned)entry_x >> 16));
+        const int4 lo = sp[0], hi = sp[1];   // (pcm_off, base), (pcm_bytes, n_frames, x_tile0, y_tile0)
+        auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        const long long pcm_off = (long long)(((unsigned long long)(unsigned)rfl(lo.y) << 32) | (unsigned)rfl(lo.x));
+        ts.pcm_base = a.pcm_base + pcm_off;
+        ts.base = (long long)(((unsigned long long)(unsigned)rfl(lo.w) << 32) | (unsigned)rfl(lo.z));
+        ts.pcm_bytes = (unsigned)rfl(hi.x);
+        ts.n_frames = rfl(hi.y);
+        ts.xt0 = rfl(hi.z);
+        ts.yt0 = rfl(hi.w);
+    }
+    return ts;
+}
 template <int BM = FT_BM>
-__device__ __forceinline__ FusedTile fused_tile_of(const GemmTreeArgs& a, const int4& e) {   // tile list entry: (group, column tile, first frame, slot)
+__device__ __forceinline__ FusedTile fused_tile_of(const GemmTreeArgs& a, const int4& e, const TileStream& ts) {   // tile list entry: (group, column tile, first frame, slot)
     FusedTile t;
     t.G = a.gv[e.x];
     t.S = BM - t.G.nb_f + 1;
-    t.nfr = a.n_frames + t.G.nb - t.G.nb_f;
+    t.nfr = ts.n_frames + t.G.nb - t.G.nb_f;
+    t.xt0 = ts.xt0;
+    t.yt0 = ts.yt0;
     t.ntl = e.y;
     t.f0 = e.z;
     t.nt = t.G.tile0 + t.ntl;
     return t;
 }
 template <int BM = FT_BM>
-__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a) {   // (the kernels of 32-column tiles: their lists carry no wide entries)
+__device__ __forceinline__ FusedTile fused_tile(const GemmTreeArgs& a, TileStream& ts) {   // (the kernels of 32-column tiles: their lists carry no wide entries)
     int4 e = a.tile_list[blockIdx.x];
+    ts = tile_stream(a, e.x);
     e.x &= 7;
-    return fused_tile_of<BM>(a, e);
+    return fused_tile_of<BM>(a, e, ts);
 }
 
 // doubling tree over the [128][32 complex] P tile in LDS (rows padded to 33 so that the transposed store
@@ -366,7 +425,8 @@ __device__ __forceinline__ void fused_store_x(float* smem, const FusedTile& t, c
     const int f = t.f0 + j;
     if (j < t.S && f < t.nfr) {
         // windows of more than 64 blocks: 64-block partial sums go to Y, blockdft_tree_finish adds the last levels
-        float2* dst = (t.G.nb > t.G.nb_f ? a.Y : a.X) + ((size_t)(f >> 6) * a.xcp + t.nt * CB_C) * 64 + (f & 63);
+        const bool to_y = t.G.nb > t.G.nb_f;
+        float2* dst = (to_y ? a.Y : a.X) + ((size_t)((f >> 6) + (to_y ? t.yt0 : t.xt0)) * a.xcp + t.nt * CB_C) * 64 + (f & 63);
         const int ncv = t.G.n_cols - t.ntl * CB_C < CB_C ? t.G.n_cols - t.ntl * CB_C : CB_C;   // the tile's real columns: the padding of a group's last tile is never read with a non-zero coefficient and never written (X starts out zeroed)
 #pragma unroll 4
         for (int cc = tid / BM; cc < ncv; cc += 2) {   // streamed out (non-temporal): the kernel-product stage that reads X back runs 5 % faster for it
@@ -481,12 +541,12 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
 // E slice, (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}) as one 16-byte LDS read.  Operands double-buffered, one k group ahead.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <int BM, bool HALF>   // tiles that lie wholly inside the stream (all but a handful per launch); HALF: at most 16 columns (a group's last tile): the second 16-column half is not computed
-__device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
+__device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, long long tile_lo, const float4* e_tile, int tid,
                                                   f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
     constexpr int THREADS = 2 * BM;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
-    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
-    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)pcm_bytes, 0x00020000};
     const int K2 = a.K / 2;
     const int nG = K2 / 32;   // (K2 is a multiple of 32: the fused path takes hops that are multiples of 64)
     // A load step fetches a DOUBLE k group (32 mirrored sample pairs): lane (row, kq) takes the 8 consecutive samples 32 G + 8 kq ...
@@ -602,11 +662,11 @@ __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, float* 
 // the same order — k group g = 2 G + h — but one 16-pair half of a double group per load step, which keeps its 32 dword loads
 // per step inside the register budget.
 template <int BM>
-__device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
+__device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, long long tile_lo, const float4* e_tile, int tid,
                                                        f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
     constexpr int THREADS = 2 * BM;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm_base), 0, pcm_bytes, 0x00020000);
     const int K2 = a.K / 2;
     int jf0[2], jb0[2];   // sample indices relative to pcm_base (|.| < 2^30: the launch's stream is at most 4 GB)
 #pragma unroll
@@ -671,12 +731,12 @@ __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, fl
 // loads of group G + 1 are in flight, and so on in turn.  Every accumulator adds the same products in the same order as in the
 // narrow loop: results are bit-identical whichever form a tile takes.  The two tiles' slices of E lie 32 KB apart in LDS.
 template <int BM>
-__device__ __forceinline__ void fused_f32_kloop64(const GemmTreeArgs& a, float* smem, long long tile_lo, const float4* e_tile, int tid,
+__device__ __forceinline__ void fused_f32_kloop64(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, long long tile_lo, const float4* e_tile, int tid,
                                                   f32x4a (&accR)[2][4], f32x4a (&accI)[2][4], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
     constexpr int THREADS = 2 * BM, NWV = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
-    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
-    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)pcm_bytes, 0x00020000};
     const int K2 = a.K / 2;
     const int nG = K2 / 32;
     unsigned vf[2], vb[2];
@@ -783,7 +843,7 @@ __device__ __forceinline__ void fused_dump_p(float* smem, const f32x4a (&accR)[2
 
 // one 32-column tile from the K loop to the store
 template <int BM>
-__device__ __forceinline__ void fused_f32_narrow_tile(const GemmTreeArgs& a, float* smem, float2 (*tw_lds)[CB_C], const FusedTile& T, bool inside,
+__device__ __forceinline__ void fused_f32_narrow_tile(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, float2 (*tw_lds)[CB_C], const FusedTile& T, bool inside,
                                                       long long tile_lo, int tid, int stamp_slot) {
     const int lane = tid & 63;
     // the tile's combine twiddles (levels x 32 complex columns = 64 floats per level): a wave copies a level, a dword per lane
@@ -810,11 +870,11 @@ __device__ __forceinline__ void fused_f32_narrow_tile(const GemmTreeArgs& a, flo
     // a group's last column tile may hold 16 columns or fewer (3 of the 21 tiles at 48 kHz / 252 bins): half the MFMAs
     const bool half = T.ntl == T.G.n_tiles - 1 && T.G.n_cols - T.ntl * CB_C <= 16;
     if (!inside)
-        fused_f32_kloop16_edge<BM>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+        fused_f32_kloop16_edge<BM>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     else if (half)
-        fused_f32_kloop16<BM, true>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+        fused_f32_kloop16<BM, true>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     else
-        fused_f32_kloop16<BM, false>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+        fused_f32_kloop16<BM, false>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -848,15 +908,16 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     __shared__ float2 tw_lds[2][FT_MAXL][CB_C];
     const unsigned long long t_entry = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63;
-    const int4 entry = a.tile_list[blockIdx.x];   // .x: group | wide << 8
-    FusedTile T = fused_tile_of<BM>(a, make_int4(entry.x & 7, entry.y, entry.z, entry.w));   // (gv[8])
-    const bool wide = (entry.x >> 8) != 0;
+    const int4 entry = a.tile_list[blockIdx.x];   // .x: group | wide << 8 | segment << 16
+    const TileStream ts = tile_stream(a, entry.x);
+    FusedTile T = fused_tile_of<BM>(a, make_int4(entry.x & 7, entry.y, entry.z, entry.w), ts);   // (gv[8])
+    const bool wide = ((entry.x >> 8) & 1) != 0;
     if (T.f0 >= T.nfr) return;
     const int stamp_slot = blockIdx.x;
     PVQ_STAMP(0);
-    const long long s = a.base + T.G.s_rel;
+    const long long s = ts.base + T.G.s_rel;
     const long long tile_lo = s + (long long)T.f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
-    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes;
+    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)ts.pcm_bytes;
     if (WIDE && wide && inside) {
         const float* tw_src = reinterpret_cast<const float*>(a.comb_tw + T.G.tw_off + T.ntl * CB_C) + lane;
         float* tw_dst = reinterpret_cast<float*>(&tw_lds[0][0][0]);
@@ -875,7 +936,7 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
             a.clk[(blockIdx.x >> 6) * 4 + 0] = __builtin_amdgcn_s_memtime();
             a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         }
-        fused_f32_kloop64<BM>(a, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, T.G.levels_f, 2 * T.G.n_tiles * CB_C, stamp_slot);
+        fused_f32_kloop64<BM>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, T.G.levels_f, 2 * T.G.n_tiles * CB_C, stamp_slot);
         if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
             a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
             a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -898,7 +959,7 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
         return;
     }
     // (the host pairs only tiles that lie inside the stream — same test, same numbers, launch(): the range-checked loop takes one tile)
-    fused_f32_narrow_tile<BM>(a, smem, tw_lds[0], T, inside, tile_lo, tid, stamp_slot);
+    fused_f32_narrow_tile<BM>(a, ts.pcm_base, ts.pcm_bytes, smem, tw_lds[0], T, inside, tile_lo, tid, stamp_slot);
     PVQ_END_STAMPS
 }
 
@@ -969,14 +1030,14 @@ __device__ __forceinline__ int fb_off(int row, int ch) { return row * FB_BK + ((
 // thread's 16 consecutive samples come as four 16-byte loads; otherwise (tiles that touch the stream start
 // or end) as 16 dword loads, each range-checked by the buffer hardware.
 template <bool VEC, int BM>
-__device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, unsigned char* smem_raw, long long a_idx0, const __bf16* e_ptr,
+__device__ __forceinline__ void fused_bf16x3_kloop(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, unsigned char* smem_raw, long long a_idx0, const __bf16* e_ptr,
                                                    int tid, f32x16& acc0, f32x16& acc1) {
     constexpr int FB_PLANE = FbGeom<BM>::PLANE;
     __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(a.pcm_base);
-    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)a.pcm_bytes, 0x00020000};
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pcm_base), 0, a.pcm_bytes, 0x00020000);
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)pcm_bytes, 0x00020000};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm_base), 0, pcm_bytes, 0x00020000);
     // A staging: thread -> (row = tid / 2, 16 consecutive k); B staging: thread -> (n = tid / 4, 8 consecutive k) x 3 planes
     const int a_row = tid >> 1, b_n = tid >> 2;
     const size_t plane = (size_t)a.ld * a.K;
@@ -1069,12 +1130,13 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
     __shared__ float2 tw_lds[FT_MAXL][CB_C];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FusedTile T = fused_tile<BM>(a);
+    TileStream ts;
+    const FusedTile T = fused_tile<BM>(a, ts);
     const int f0 = T.f0, nt = T.nt;
     if (f0 >= T.nfr) return;
     if (tid < 256) fused_stage_twiddles(tw_lds, T, a, tid);
     const int wm = wave >> 1, wn = wave & 1;
-    const long long s = a.base + T.G.s_rel;
+    const long long s = ts.base + T.G.s_rel;
     const long long tile_lo = s + (long long)f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;  // sample range of the tile
     const long long a_off0 = tile_lo + (long long)(tid >> 1) * a.K + (tid & 1) * 16;   // sample index of the thread's 16-sample run
     const __bf16* e_ptr = a.Et + (size_t)(nt * FT_BN + ((tid & 255) >> 2)) * a.K + (tid & 3) * 8;
@@ -1084,10 +1146,10 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 4 : 2) void blockdft_gemm_tree_
         acc0[q] = 0.0f;
         acc1[q] = 0.0f;
     }
-    if (tile_lo >= 0 && tile_hi * 4ll <= (long long)a.pcm_bytes)
-        fused_bf16x3_kloop<true, BM>(a, smem_raw, a_off0, e_ptr, tid, acc0, acc1);
+    if (tile_lo >= 0 && tile_hi * 4ll <= (long long)ts.pcm_bytes)
+        fused_bf16x3_kloop<true, BM>(a, ts.pcm_base, ts.pcm_bytes, smem_raw, a_off0, e_ptr, tid, acc0, acc1);
     else
-        fused_bf16x3_kloop<false, BM>(a, smem_raw, a_off0, e_ptr, tid, acc0, acc1);
+        fused_bf16x3_kloop<false, BM>(a, ts.pcm_base, ts.pcm_bytes, smem_raw, a_off0, e_ptr, tid, acc0, acc1);
     const int bc = wn * 32 + (lane & 31);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1115,17 +1177,23 @@ struct FinishArgs {
     int n_real;        // columns of the group that exist (the padding is neither written by the fused kernel nor combined here)
     int levels_f, levels;
     const float2* tw;  // the group's combine twiddles: [levels][n_cols]
+    const XTile* xmap; // many-streams launches: per X tile, the Y tile of the same frames and the number of frames that exist
 };
 __global__ __launch_bounds__(256) void blockdft_tree_finish(FinishArgs a) {
     const int fr = threadIdx.x & 63, cc = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int tile = blockIdx.x;
-    if (cc >= a.n_real || tile * 64 + fr >= a.n_frames) return;
+    int ytile = tile, n_live = a.n_frames - tile * 64;
+    if (a.xmap) {
+        ytile = a.xmap[tile].y_tile;
+        n_live = a.xmap[tile].n_live;
+    }
+    if (cc >= a.n_real || fr >= n_live) return;
     const int col = a.col0 + cc;
     const int nq = 1 << (a.levels - a.levels_f);   // 2 or 4
     float2 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (q < nq) v[q] = a.Y[((size_t)(tile + q) * a.xcp + col) * 64 + fr];
+        if (q < nq) v[q] = a.Y[((size_t)(ytile + q) * a.xcp + col) * 64 + fr];
     const float2 w0 = a.tw[(size_t)a.levels_f * a.n_cols + cc];
     if (nq == 2) {
         v[0] = tree_cmadd(v[0], w0, v[1]);
@@ -1233,6 +1301,7 @@ struct BandArgs {
     float* out_db;             // [n_frames][n_bins]
     float2* out_cplx;          // optional
     unsigned* status;          // the handle's sticky flag word: bit 0 <- a live frame holds a non-finite power value
+    const XTile* xmap;         // many-streams launches: per X tile, its output rows and how many of its frames exist (nullptr: tile t holds rows 64 t ...)
     unsigned long long* stamps;   // developer knob PVQ_STAMPS_DOTS: [workgroup][8] 100 MHz clock: 0 start, 1 wave 0 done with its blocks, 2 all waves done, 3 end
 };
 
@@ -1277,7 +1346,7 @@ __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 constexpr int BAND_LDB2 = 260;   // the 64-frame form: up to 256 bins + 4 (rows 4 apart land 16 banks apart)
 constexpr int BAND_LDB3 = 308;   // the 64-frame 8-bin form up to 304 bins (78.8 KB: still two workgroups per CU)
 template <int MT, int LDB>
-__device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, int f0, int bin0, int nrows,
+__device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, long long row0, int n_live, int bin0, int nrows,
                                               int lane) {
     const int ldb = LDB ? LDB : a.ldb;
     const int n = lane & 31, kx = lane >> 5;
@@ -1305,7 +1374,7 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                    if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * row_stride + bin] = make_float2(acc[mt][q], im[q]);
+                    if (fr < n_live) a.out_cplx[(size_t)(row0 + fr) * row_stride + bin] = make_float2(acc[mt][q], im[q]);
                 }
             }
         }
@@ -1316,7 +1385,7 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 // time with their dB values in registers, so the read -> log -> reduce -> rescale chains of the frames overlap
 // (the phase is latency-bound at two waves per SIMD); more bins: one frame at a time through LDS.
 template <int MT, int NW, int LDB = (MT == 2 ? BAND_LDB2 : 0)>
-__device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f0, int wave, int lane) {
+__device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, long long row0, int n_live, int wave, int lane) {
     const int ldb = LDB ? LDB : a.ldb;
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
@@ -1335,7 +1404,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
             for (int u = 0; u < FU; ++u) {
                 mx[u] = -3.40282347e+38f;
                 mn[u] = 3.40282347e+38f;
-                const bool live = f0 + fr0 + NW * u < a.n_frames;
+                const bool live = fr0 + NW * u < n_live;
 #pragma unroll
                 for (int kk = 0; kk < NKB; ++kk) {
                     const int k = lane + 64 * kk;
@@ -1355,10 +1424,10 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 const int fr = fr0 + NW * u;
-                if (f0 + fr >= a.n_frames) continue;
+                if (fr >= n_live) continue;
                 const float floor_db = mx[u] - PVQ_TOP_DB;
                 const float m2 = fmaxf(mn[u], floor_db);
-                float* dst = a.out_db + (size_t)(f0 + fr) * a.n_bins;
+                float* dst = a.out_db + (size_t)(row0 + fr) * a.n_bins;
 #pragma unroll
                 for (int kk = 0; kk < NKB; ++kk) {
                     const int k = lane + 64 * kk;
@@ -1379,7 +1448,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
         return;
     }
     for (int fr = wave; fr < MT * 32; fr += NW) {
-        if (f0 + fr >= a.n_frames) break;
+        if (fr >= n_live) break;
         float* rowp = dbs + fr * ldb;
         float mx = -3.40282347e+38f, mn = 3.40282347e+38f;
         for (int k = lane; k < a.n_bins; k += 64) {
@@ -1393,7 +1462,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, int f
         mn = wave_min(mn);
         const float floor_db = mx - PVQ_TOP_DB;
         const float m2 = fmaxf(mn, floor_db);
-        float* dst = a.out_db + (size_t)(f0 + fr) * a.n_bins;
+        float* dst = a.out_db + (size_t)(row0 + fr) * a.n_bins;
         for (int k = lane; k < a.n_bins; k += 64) {
             const float c = fmaxf(rowp[k], floor_db);
             dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
@@ -1411,6 +1480,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
     const int n = lane & 31, kx = lane >> 5;
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
+    // the output rows of this workgroup's frames: rows f0 ... of a single stream, or what the X tile's entry of the map says
+    long long row0 = f0;
+    int n_live = a.n_frames - f0;
+    if (a.xmap) {   // (uniform)
+        const XTile xt = a.xmap[f0 >> 6];
+        row0 = xt.out_row0 + (f0 & 63);
+        n_live = xt.n_live - (f0 & 63);
+    }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
     const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
@@ -1488,12 +1565,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
             blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
             open_block(blk);
         }
-        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, f0, bin0, nrows, lane);
+        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, row0, n_live, bin0, nrows, lane);
     }
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<MT, NW>(dbs, a, f0, wave, lane);
+    band_finish<MT, NW>(dbs, a, row0, n_live, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1522,6 +1599,14 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
     const int f0 = blockIdx.x * (32 * NU);
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // (a half-tile workgroup starts at frame pair 16 of its tile)
+    // the output rows of this workgroup's frames: rows f0 ... of a single stream, or what the X tile's entry of the map says
+    long long row0 = f0;
+    int n_live = a.n_frames - f0;
+    if (a.xmap) {   // (uniform)
+        const XTile xt = a.xmap[f0 >> 6];
+        row0 = xt.out_row0 + (f0 & 63);
+        n_live = xt.n_live - (f0 & 63);
+    }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
     const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
@@ -1605,7 +1690,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int fr = 32 * u + 8 * kq + 2 * q + p;
-                            if (f0 + fr < a.n_frames) a.out_cplx[(size_t)(f0 + fr) * row_stride + bin] = make_float2(acc[u][p][q], im[q]);
+                            if (fr < n_live) a.out_cplx[(size_t)(row0 + fr) * row_stride + bin] = make_float2(acc[u][p][q], im[q]);
                         }
                     }
                 }
@@ -1614,7 +1699,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<NU, NW, LDB>(dbs, a, f0, wave, lane);
+    band_finish<NU, NW, LDB>(dbs, a, row0, n_live, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1639,6 +1724,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
     const int n = lane & 31, kx = lane >> 5;
     constexpr int col_stride = 128;   // floats between consecutive X columns of a 64-frame tile
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
+    // the output rows of this workgroup's frames: rows f0 ... of a single stream, or what the X tile's entry of the map says
+    long long row0 = f0;
+    int n_live = a.n_frames - f0;
+    if (a.xmap) {   // (uniform)
+        const XTile xt = a.xmap[f0 >> 6];
+        row0 = xt.out_row0 + (f0 & 63);
+        n_live = xt.n_live - (f0 & 63);
+    }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
     const int n_blocks = __builtin_amdgcn_readfirstlane(my_list[0]);
@@ -1717,12 +1810,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
             blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
             open_block(blk);
         }
-        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, f0, bin0, nrows, lane);
+        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, row0, n_live, bin0, nrows, lane);
     }
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<MT, NW>(dbs, a, f0, wave, lane);
+    band_finish<MT, NW>(dbs, a, row0, n_live, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1765,6 +1858,15 @@ float Vqt::last_sclk_mhz() {
 }
 
 uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_t)(dev_->block->n_tiles * CB_C) : 0u; }
+
+// whether the block-DFT path can take several streams in one launch (the fused GEMM + tree kernels; the unfused fallback stages —
+// more than 8 window groups — run one stream per call)
+bool Vqt::blockdft_takes_streams(size_t hop) {
+    if (!blockdft_applicable(hop) || prepare_blockdft(hop) != PVQ_OK) return false;
+    const BlockDftTables* t = dev_->block;
+    const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
+    return !dev_knob("PVQ_NO_FUSE", 0) && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
+}
 
 bool Vqt::blockdft_applicable(size_t hop) const {
     if (!has_device() || hop < 64 || (hop & (hop - 1)) != 0 || hop > 4096) return false;   // the mirrored K loop walks hop / 2 in stages of 32
@@ -2121,16 +2223,71 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
 // the streams contend for the same CUs.)
 pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                      float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
-    pvq_status st = prepare_blockdft(hop);
-    if (st != PVQ_OK) return st;
+    const StreamIn one{d_pcm, n_lead, n_frames, 0};
+    return launch_blockdft_streams(&one, 1, hop, d_out_db, d_out_cplx, n_frames, pk, stream);
+}
+
+// The same path over MANY streams (pvq_vqt_*_streams).  Every stream is cut into runs of at most one sub-batch; runs are packed
+// into launches up to the sub-batch size (the workspace limit), so 64 streams of 2 048 frames are ONE launch per stage where a
+// loop over single-stream calls pays 64 ramps and tails per stage; a long stream still runs sub-batch by sub-batch, alone in
+// its launches, exactly as through the single-stream entry point.  Stream s writes its rows to out rows st[s].out_row0 ...
+pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t hop, float* d_out_db, float* d_out_cplx, size_t rows_total,
+                                        const PeakParamsDev* pk, hipStream_t stream) {
+    pvq_status pst = prepare_blockdft(hop);
+    if (pst != PVQ_OK) return pst;
     BlockDftTables* t = dev_->block;
     const int ntot = t->n_tiles * GM_BN, xc = t->n_tiles * CB_C;
     // X is blocked by 64-frame tiles: [tile][column][64 frames], so the kernel-product workgroup of a tile streams one
     // contiguous region (and a column step is a constant 512 bytes); X_PAD_COLS zeroed columns close every tile
     const int xcp = xc + X_PAD_COLS;
-    const size_t chunk = std::min(n_frames, chunk_frames(workspace_limit_, (size_t)xcp * sizeof(float2) * (t->nb_max > 64 ? 2 : 1)));
+    size_t longest = 0, total_frames = 0;
+    for (size_t i = 0; i < n_st; ++i) {
+        longest = std::max(longest, st[i].n_frames);
+        total_frames += st[i].n_frames;
+    }
+    const size_t chunk = std::min(n_st == 1 ? longest : std::max<size_t>((total_frames + 63) / 64 * 64, 64),
+                                  chunk_frames(workspace_limit_, (size_t)xcp * sizeof(float2) * (t->nb_max > 64 ? 2 : 1)));
+    const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
+    static const bool fuse_env = !dev_knob("PVQ_NO_FUSE", 0);
+    const bool fused = fuse_env && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
+    if (!fused && n_st > 1) {
+        set_last_error("internal: the unfused block-DFT stages take one stream per call");
+        return PVQ_ERR_INTERNAL;
+    }
+    // runs -> launches: a launch holds runs of whole 64-frame tiles up to the sub-batch size
+    struct Run { size_t stream, fbeg, nf; };
+    std::vector<std::vector<Run>> launches;
+    {
+        const size_t budget = (chunk + 63) / 64;   // tiles per launch
+        size_t used = 0;
+        for (size_t i = 0; i < n_st; ++i) {
+            size_t fbeg = 0, left = st[i].n_frames;
+            while (left > 0) {
+                const size_t nf = std::min(left, chunk);
+                const size_t tiles = (nf + 63) / 64;
+                if (launches.empty() || used + tiles > budget) {
+                    launches.emplace_back();
+                    used = 0;
+                }
+                launches.back().push_back(Run{i, fbeg, nf});
+                used += tiles;
+                fbeg += nf;
+                left -= nf;
+            }
+        }
+    }
+    size_t x_tiles = 1, y_tiles = 1;
+    for (const auto& L : launches) {
+        size_t xt = 0, yt = 0;
+        for (const Run& r : L) {
+            xt += (r.nf + 63) / 64;
+            yt += (r.nf + (size_t)std::max(t->nb_max - 64, 0) + 63) / 64;
+        }
+        x_tiles = std::max(x_tiles, xt);
+        y_tiles = std::max(y_tiles, yt);
+    }
     const size_t rows_cap = chunk + t->nb_max - 1;
-    const size_t x_bytes = (chunk + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
+    const size_t x_bytes = x_tiles * (size_t)xcp * 64 * sizeof(float2);
     if (t->x_cap < x_bytes) {
         if (t->d_X) PVQ_HIP(hipFree(t->d_X));
         t->d_X = nullptr; t->x_cap = 0;
@@ -2138,11 +2295,8 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         PVQ_HIP(hipMemsetAsync(t->d_X, 0, x_bytes, stream));
         t->x_cap = x_bytes;
     }
-    const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
-    static const bool fuse_env = !dev_knob("PVQ_NO_FUSE", 0);
-    const bool fused = fuse_env && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
     if (fused && t->nb_max > 64) {
-        const size_t y_bytes = (chunk + (size_t)(t->nb_max - 64) + 63) / 64 * (size_t)xcp * 64 * sizeof(float2);
+        const size_t y_bytes = y_tiles * (size_t)xcp * 64 * sizeof(float2);
         if (t->y_cap < y_bytes) {
             if (t->d_Y) PVQ_HIP(hipFree(t->d_Y));
             t->d_Y = nullptr; t->y_cap = 0;
@@ -2159,7 +2313,6 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             t->p_cap = p_bytes;
         }
     }
-    const long long n_samples = (long long)(n_lead + n_frames * hop);
     if (use_bf && fused && !t->d_Et) {
         // bf16 split of E^T (round-to-nearest-even on the bit patterns), built on first use
         std::vector<uint16_t> Et((size_t)3 * ntot * hop);
@@ -2177,20 +2330,42 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         PVQ_HIP(hipMemcpy(t->d_Et, Et.data(), Et.size() * 2, hipMemcpyHostToDevice));
     }
     const int nb = (int)n_bins();
-    const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     float2* X = t->d_X;
-    for (size_t c = 0; c < n_chunks; ++c) {
-        const size_t fbeg = c * chunk;
-        const size_t nf = std::min(chunk, n_frames - fbeg);
-        // rebase the stream so that every byte offset of this launch fits 32 bits
-        const long long first_needed = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop -
-                                       (long long)plan_.params.n_fft;
-        const long long rebase = std::max<long long>(0, std::min<long long>(first_needed, n_samples));
-        const long long extent = std::min<long long>(n_samples - rebase, (long long)(nf + 2) * (long long)hop +
-                                                                            (long long)plan_.params.n_fft + 4096);
-        const float* pcm_base = d_pcm + rebase;
-        const unsigned pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
-        const long long base = (long long)n_lead + (long long)hop + (long long)fbeg * (long long)hop - rebase;
+    // the launch's base pointer: the lowest stream pointer (segment offsets are counted from it, in samples)
+    const float* pcm_min = st[0].d_pcm;
+    for (size_t i = 1; i < n_st; ++i)
+        if (st[i].d_pcm < pcm_min) pcm_min = st[i].d_pcm;
+    for (const auto& L : launches) {
+        // per run: rebase its stream so that every byte offset of the launch fits 32 bits
+        const bool multi = L.size() > 1;
+        std::vector<BlockDftTables::SegKey> segs(L.size());
+        size_t xt_n = 0, yt_n = 0, nf_launch = 0;
+        for (size_t u = 0; u < L.size(); ++u) {
+            const Run& r = L[u];
+            const StreamIn& S = st[r.stream];
+            const long long n_samples = (long long)(S.n_lead + S.n_frames * hop);
+            const long long first_needed = (long long)S.n_lead + (long long)hop + (long long)r.fbeg * (long long)hop - (long long)plan_.params.n_fft;
+            const long long rebase = std::max<long long>(0, std::min<long long>(first_needed, n_samples));
+            const long long extent = std::min<long long>(n_samples - rebase, (long long)(r.nf + 2) * (long long)hop + (long long)plan_.params.n_fft + 4096);
+            BlockDftTables::SegKey& k = segs[u];
+            k.pcm_off = (long long)(S.d_pcm - pcm_min) + rebase;
+            k.pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
+            k.base = (long long)S.n_lead + (long long)hop + (long long)r.fbeg * (long long)hop - rebase;
+            k.nf = (int)r.nf;
+            k.x_tile0 = (int)xt_n;
+            k.y_tile0 = (int)yt_n;
+            k.out_row0 = (long long)(S.out_row0 + r.fbeg);
+            xt_n += (r.nf + 63) / 64;
+            yt_n += (r.nf + (size_t)std::max(t->nb_max - 64, 0) + 63) / 64;
+            nf_launch += r.nf;
+        }
+        // a launch of one run goes through the kernel arguments (segs == nullptr), as the single-stream entry point always did
+        const float* pcm_base = multi ? pcm_min : pcm_min + segs[0].pcm_off;
+        const unsigned pcm_bytes = segs[0].pcm_bytes;
+        const long long base = segs[0].base;
+        const size_t nf = multi ? xt_n * 64 : (size_t)segs[0].nf;   // frames the per-frame stages of the launch cover
+        const SegDev* d_segs = nullptr;
+        const XTile* d_xmap = nullptr;
         if (fused) {
             GemmTreeArgs fa;
             fa.pcm_base = pcm_base;
@@ -2200,7 +2375,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             fa.X = X;
             fa.Y = t->d_Y;
             fa.xcp = xcp;
-            fa.n_frames = (int)nf;
+            fa.n_frames = (int)segs[0].nf;
             fa.K = (int)hop;
             fa.base = base;
             fa.n_groups = t->n_groups;
@@ -2209,18 +2384,19 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             // 256-row tiles: 257 - Nb complete frames per tile (1.08x row recomputation instead of 1.2x with 128 rows)
             const int fused_bm = bm_env == 128 && !use_bf ? 128 : 256;
             double eff_tiles = 0.0;   // matrix work of the launch in whole-tile units
-            for (int g = 0; g < t->n_groups; ++g) {
-                const int S = fused_bm - t->groups[g].nb_f + 1;
-                const int rows_g = (int)nf + t->groups[g].nb - t->groups[g].nb_f;
-                // a last tile of at most 16 columns runs half the MFMAs (fp32 kernel; the few tiles at the stream's ends run the full
-                // loop: counted as half all the same)
-                const bool half_last = !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
-                eff_tiles += (t->groups[g].n_tiles - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
-            }
-            // Frame-stripe tile order: the stream is cut into stripes of 2 048 frames, stripe s belongs to XCD queue s & 7 (workgroup b
+            for (const auto& k : segs)
+                for (int g = 0; g < t->n_groups; ++g) {
+                    const int S = fused_bm - t->groups[g].nb_f + 1;
+                    const int rows_g = k.nf + t->groups[g].nb - t->groups[g].nb_f;
+                    // a last tile of at most 16 columns runs half the MFMAs (fp32 kernel; the few tiles at the stream's ends run the full
+                    // loop: counted as half all the same)
+                    const bool half_last = !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
+                    eff_tiles += (t->groups[g].n_tiles - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
+                }
+            // Frame-stripe tile order: the launch's frames are cut into stripes of 2 048, stripe s belongs to XCD queue s & 7 (workgroup b
             // runs on the XCD of all b' = b mod 8), and a queue takes its stripes in order, within a stripe every group's row tiles with
             // all their column tiles.  All window groups then read a stripe's PCM rows from that XCD's L2 while they are resident (once
-            // per stripe, not once per group).  Entry: (group, column tile, first frame, position i * 8 + queue).
+            // per stripe, not once per group).  Entry: (group | wide << 8 | segment << 16, column tile, first frame, position i * 8 + queue).
             static const int FS = dev_knob("PVQ_TILE_FS", 2048);
             static const int balance_env = dev_knob("PVQ_BALANCE", 1);   // 0: queues as the stripes fall
             static const int order_env = dev_knob("PVQ_ORDER", 1);       // 0: wide and narrow tiles of a stripe interleaved
@@ -2228,43 +2404,60 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
             static const int tail_env = dev_knob("PVQ_TAIL", 128);       // narrow entries at the end of every queue
             static const int wide_env = dev_knob("PVQ_WIDE", 1);         // 0: narrow tiles only; 2: wide tiles to the very end of every queue; 3: none in a queue's last stripe
             const int wide_mode = !use_bf && fused_bm == 256 ? wide_env : 0;   // (the split-bf16 kernel and the 128-row form take 32-column tiles only)
+            if (segs.size() > 0xFFFFu) {
+                set_last_error("too many streams in one launch");
+                return PVQ_ERR_INTERNAL;
+            }
+            // The list is cached per (tile rows, kernel family, the runs' stream geometry): which tiles lie wholly inside their stream —
+            // 16-byte loads, wide entries — is decided here with the kernel's own test, so a list built for one geometry must never be
+            // used for another (round 3: a list keyed on the frame count alone let a launch read past a shorter stream's end)
+            // (a launch of one run hands its stream pointer and output rows over in the kernel arguments: they are not part of its key,
+            // so the middle sub-batches of a long stream share one list, and so do different buffers of one geometry)
+            std::vector<BlockDftTables::SegKey> key = segs;
+            if (!multi) key[0].pcm_off = key[0].out_row0 = 0;
             BlockDftTables::TileList* tl = nullptr;
             for (auto& c : t->tile_lists)
-                if (c.nf == (int)nf && c.bm == fused_bm && c.wide == wide_mode && c.base == base && c.pcm_bytes == pcm_bytes) tl = &c;
+                if (c.bm == fused_bm && c.wide == wide_mode && c.multi == multi && c.key == key) tl = &c;
             if (!tl) {
                 tl = &t->tile_lists[t->tile_list_next];
                 t->tile_list_next = (t->tile_list_next + 1) & 3;
-                std::vector<std::vector<int4>> q(8);
-                for (int g = 0; g < t->n_groups; ++g) {
+                auto grp = [](const int4& e) { return e.x & 255; };
+                auto is_wide = [](const int4& e) { return ((e.x >> 8) & 1) != 0; };
+                auto seg_of = [](const int4& e) { return (int)((unsigned)e.x >> 16); };
+                auto inside_of = [&](int g, int seg, int f0) {   // the kernel's own test
                     const BlockGroup& G = t->groups[g];
-                    const int S = fused_bm - G.nb_f + 1;
-                    const int rows_g = (int)nf + G.nb - G.nb_f;
-                    const bool half_last = G.n_cols - (G.n_tiles - 1) * CB_C <= 16;
-                    for (int f0 = 0; f0 < rows_g; f0 += S)
-                        for (int ntl = 0; ntl < G.n_tiles; ++ntl) {
-                            // two neighbouring column tiles as one WIDE entry (.x bit 8; fp32 kernel, 256-row tiles)
-                            const long long tile_lo = base + G.s_rel + (long long)f0 * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
-                            const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)pcm_bytes;   // the kernel's own test
-                            // (a last tile of at most 16 columns keeps its own entry and its half-depth loop)
-                            const bool pair = wide_mode && inside && ntl + 1 < G.n_tiles && (pair_half_env || !(half_last && ntl + 1 == G.n_tiles - 1));
-                            q[(f0 / FS) & 7].push_back(make_int4(g | (pair ? 256 : 0), ntl, f0, f0 / FS));
-                            if (pair) ++ntl;
-                        }
-                }
-                size_t L = 0;
+                    const long long tile_lo = segs[seg].base + G.s_rel + (long long)f0 * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
+                    return tile_lo >= 0 && tile_hi * 4ll <= (long long)segs[seg].pcm_bytes;
+                };
+                std::vector<std::vector<int4>> q(8);
+                for (size_t u = 0; u < segs.size(); ++u)
+                    for (int g = 0; g < t->n_groups; ++g) {
+                        const BlockGroup& G = t->groups[g];
+                        const int S = fused_bm - G.nb_f + 1;
+                        const int rows_g = segs[u].nf + G.nb - G.nb_f;
+                        const bool half_last = G.n_cols - (G.n_tiles - 1) * CB_C <= 16;
+                        for (int f0 = 0; f0 < rows_g; f0 += S)
+                            for (int ntl = 0; ntl < G.n_tiles; ++ntl) {
+                                // two neighbouring column tiles as one WIDE entry (.x bit 8; fp32 kernel, 256-row tiles)
+                                // (a last tile of at most 16 columns keeps its own entry and its half-depth loop)
+                                const bool pair = wide_mode && inside_of(g, (int)u, f0) && ntl + 1 < G.n_tiles && (pair_half_env || !(half_last && ntl + 1 == G.n_tiles - 1));
+                                const int stripe = (segs[u].x_tile0 * 64 + f0) / FS;   // position in the launch's frame order
+                                q[stripe & 7].push_back(make_int4(g | (pair ? 256 : 0) | (int)((unsigned)u << 16), ntl, f0, stripe));
+                                if (pair) ++ntl;
+                            }
+                    }
+                size_t Lq = 0;
                 // what a tile costs its workgroup, roughly in us: K loop (half for a last tile of at most 16 columns) + tree levels
                 auto tile_cost = [&](const int4& e) {
-                    const BlockGroup& G = t->groups[e.x & 255];
+                    const BlockGroup& G = t->groups[grp(e)];
                     const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
-                    const long long tile_lo = base + G.s_rel + (long long)e.z * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
-                    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)pcm_bytes;
-                    if (!inside) return 2 * 16 + G.levels_f;   // the range-checked loop: dword loads
-                    return ((half ? 8 : 16) + G.levels_f) * (e.x >> 8 ? 2 : 1);
+                    if (!inside_of(grp(e), seg_of(e), e.z)) return 2 * 16 + G.levels_f;   // the range-checked loop: dword loads
+                    return ((half ? 8 : 16) + G.levels_f) * (is_wide(e) ? 2 : 1);
                 };
-                for (auto& v : q)   // by stripe; (group, row tile, column tile) order kept
+                for (auto& v : q)   // by stripe; (segment, group, row tile, column tile) order kept
                     std::stable_sort(v.begin(), v.end(), [&](const int4& x, const int4& y) {
                         if (x.w != y.w) return x.w < y.w;
-                        return order_env ? (x.x >> 8) > (y.x >> 8) : false;   // wide tiles of a stripe before its narrow ones (see below)
+                        return order_env ? is_wide(x) > is_wide(y) : false;   // wide tiles of a stripe before its narrow ones (see below)
                     });
                 // Even queues: stripes are dealt round robin, but the stream's first and last stripe carry extra tiles (the range-checked
                 // ones at the ends, which do not pair up, and the long windows' partial-sum rows past the last frame) — queue 0 ran 28 us
@@ -2308,9 +2501,9 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                             while (v.size() > lo && tail.size() < n_tail) {
                                 const int4 e = v.back();
                                 v.pop_back();
-                                if (e.x >> 8) {
-                                    tail.push_back(make_int4(e.x & 255, e.y, e.z, e.w));
-                                    tail.push_back(make_int4(e.x & 255, e.y + 1, e.z, e.w));
+                                if (is_wide(e)) {
+                                    tail.push_back(make_int4(e.x & ~256, e.y, e.z, e.w));
+                                    tail.push_back(make_int4(e.x & ~256, e.y + 1, e.z, e.w));
                                 } else
                                     tail.push_back(e);
                             }
@@ -2318,38 +2511,55 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                             v.insert(v.end(), tail.begin(), tail.end());
                         }
                     }
-                    L = std::max(L, v.size());
+                    Lq = std::max(Lq, v.size());
                 }
                 tl->eff_tiles = 0.0;
                 for (auto& v : q)
                     for (const int4& e : v) {
-                        const BlockGroup& G = t->groups[e.x & 255];
+                        const BlockGroup& G = t->groups[grp(e)];
                         const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
-                        tl->eff_tiles += (e.x >> 8) ? 2.0 : (half ? 0.5 : 1.0);   // (the few range-checked tiles run the full loop: counted as half all the same)
+                        tl->eff_tiles += is_wide(e) ? 2.0 : (half ? 0.5 : 1.0);   // (the few range-checked tiles run the full loop: counted as half all the same)
                     }
-                std::vector<int4> list(8 * std::max<size_t>(L, 1), make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
+                std::vector<int4> list(8 * std::max<size_t>(Lq, 1), make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
                 for (int x = 0; x < 8; ++x) {
                     for (size_t i = 0; i < q[x].size(); ++i) {
                         list[i * 8 + x] = q[x][i];
                         list[i * 8 + x].w = (int)(i * 8 + x);
                     }
                 }
-                if (tl->cap < list.size()) {
+                // the segment table and the X-tile map travel with the list (one allocation: list | segments | map)
+                std::vector<SegDev> hsegs(segs.size());
+                std::vector<XTile> hmap(xt_n);
+                for (size_t u = 0; u < segs.size(); ++u) {
+                    hsegs[u] = SegDev{segs[u].pcm_off, segs[u].base, segs[u].pcm_bytes, segs[u].nf, segs[u].x_tile0, segs[u].y_tile0};
+                    const int tiles = (segs[u].nf + 63) / 64;
+                    for (int i = 0; i < tiles; ++i)
+                        hmap[segs[u].x_tile0 + i] = XTile{segs[u].out_row0 + 64ll * i, std::min(64, segs[u].nf - 64 * i), segs[u].y_tile0 + i};
+                }
+                const size_t b_list = list.size() * sizeof(int4), b_segs = (hsegs.size() * sizeof(SegDev) + 15) / 16 * 16, b_map = hmap.size() * sizeof(XTile);
+                if (tl->cap < b_list + b_segs + b_map) {
                     if (tl->d) PVQ_HIP(hipFree(tl->d));
                     tl->d = nullptr; tl->cap = 0;
-                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&tl->d), list.size() * sizeof(int4)));
-                    tl->cap = list.size();
+                    PVQ_HIP(hipMalloc(reinterpret_cast<void**>(&tl->d), b_list + b_segs + b_map));
+                    tl->cap = b_list + b_segs + b_map;
                 }
                 PVQ_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read this slot
-                PVQ_HIP(hipMemcpy(tl->d, list.data(), list.size() * sizeof(int4), hipMemcpyHostToDevice));
-                tl->nf = (int)nf;
+                char* dbase = reinterpret_cast<char*>(tl->d);
+                PVQ_HIP(hipMemcpy(dbase, list.data(), b_list, hipMemcpyHostToDevice));
+                PVQ_HIP(hipMemcpy(dbase + b_list, hsegs.data(), hsegs.size() * sizeof(SegDev), hipMemcpyHostToDevice));
+                PVQ_HIP(hipMemcpy(dbase + b_list + b_segs, hmap.data(), b_map, hipMemcpyHostToDevice));
+                tl->d_segs = reinterpret_cast<const SegDev*>(dbase + b_list);
+                tl->d_xmap = reinterpret_cast<const XTile*>(dbase + b_list + b_segs);
+                tl->key = key;
                 tl->bm = fused_bm;
                 tl->wide = wide_mode;
-                tl->base = base;
-                tl->pcm_bytes = pcm_bytes;
+                tl->multi = multi;
                 tl->blocks = (int)list.size();
             }
             fa.tile_list = tl->d;
+            d_segs = multi ? tl->d_segs : nullptr;
+            d_xmap = multi ? tl->d_xmap : nullptr;
+            fa.segs = d_segs;
             const int off = tl->blocks;   // list entries = workgroups of the non-persistent forms = rows of the stamp dump
             fa.groups = t->d_groups;
             for (int g = 0; g < 8; ++g) fa.gv[g] = t->groups[std::min(g, t->n_groups - 1)];
@@ -2415,6 +2625,7 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                     fin.levels_f = G.levels_f;
                     fin.levels = G.levels;
                     fin.tw = t->d_comb_tw + G.tw_off;
+                    fin.xmap = d_xmap;
                     hipLaunchKernelGGL(blockdft_tree_finish, dim3((unsigned)((nf + 63) / 64), (unsigned)((fin.n_real + 3) / 4)), dim3(256), 0,
                                        stream, fin);
                 }
@@ -2474,8 +2685,11 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
         da.B3 = t->d_band_B3;
         da.list = t->d_band_list;
         da.per_wave = t->band_per_wave;
-        da.out_db = d_out_db + fbeg * nb;
-        da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + fbeg * nb : nullptr;
+        // one run: its rows follow each other from its first output row; several: the X-tile map names every tile's rows
+        da.xmap = d_xmap;
+        const size_t row_first = multi ? 0 : (size_t)segs[0].out_row0;
+        da.out_db = d_out_db + row_first * nb;
+        da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + row_first * nb : nullptr;
         da.status = dev_->d_status;
         static const char* dstamps_env = dev_knob_str("PVQ_STAMPS_DOTS");   // dump per-workgroup phase stamps of the first launch
         static bool dstamps_done = false;
@@ -2527,16 +2741,17 @@ pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t h
                 fclose(fp);
             }
         }
+        last_frames_per_launch_ = (uint32_t)nf_launch;
     }
     if (pk) {
         slot_begin(SLOT_PEAKS, stream);
-        pvq_status ps = launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
+        pvq_status ps = launch_peaks_kernel(d_out_db, rows_total, *pk, stream);
         slot_end(SLOT_PEAKS, stream);
         if (ps != PVQ_OK) return ps;
     }
     PVQ_HIP(hipGetLastError());
     last_algo_ = PVQ_ALGO_BLOCKDFT;
-    last_frames_per_launch_ = (uint32_t)chunk;
+    if (n_st == 1) last_frames_per_launch_ = (uint32_t)chunk;
     return PVQ_OK;
 }
 

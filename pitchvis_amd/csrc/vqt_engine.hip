@@ -934,6 +934,87 @@ pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t 
     return launch_fft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
 }
 
+pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_lead, const size_t* n_frames, uint32_t n_streams, size_t hop,
+                                     float* d_out_db, size_t stride, const AnalysisParameters* ap, uint32_t* d_peak_mask, uint32_t* d_peak_count,
+                                     float* d_center, float* d_size, uint32_t max_peaks, hipStream_t stream) {
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if (n_streams == 0) return PVQ_OK;
+    if (!d_pcm || !n_frames || !d_out_db || hop == 0) {
+        set_last_error("batch_streams: null pointer or zero hop");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    if ((d_center == nullptr) != (d_size == nullptr)) {
+        set_last_error("batch_streams: only one of center/size given");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    bool ragged = false;
+    size_t total = 0;
+    for (uint32_t s = 0; s < n_streams; ++s) {
+        if (n_frames[s] > stride || n_frames[s] > (size_t)0x7fffffff) {
+            set_last_error("batch_streams: a stream has more frames than out_stride_frames (or than 2^31 - 1)");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        if (n_frames[s] > 0 && !d_pcm[s]) {
+            set_last_error("batch_streams: null stream pointer");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        ragged |= n_frames[s] != stride;
+        total += n_frames[s];
+    }
+    const size_t rows_total = (size_t)n_streams * stride;
+    if (rows_total > (size_t)0x7fffffff) {
+        set_last_error("batch_streams: more than 2^31 - 1 output rows");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    PeakParamsDev pk;
+    const bool want_peaks = ap && (d_peak_mask || d_peak_count || d_center);
+    if (want_peaks && !make_peak_params(*ap, d_peak_mask, d_peak_count, d_center, d_size, max_peaks, pk)) {
+        set_last_error("unsupported: peak detection handles 3..1024 bins per frame");
+        return PVQ_ERR_UNSUPPORTED;
+    }
+    PVQ_HIP(hipSetDevice(device_id_));
+    const size_t nb = n_bins();
+    // rows a stream does not fill are zero frames: nothing reads uninitialised memory, their peak outputs say "no peaks"
+    if (ragged) PVQ_HIP(hipMemsetAsync(d_out_db, 0, rows_total * nb * sizeof(float), stream));
+    if (total == 0) return PVQ_OK;
+    bool use_block = false;
+    if (algo_ == PVQ_ALGO_BLOCKDFT) {
+        if (!blockdft_applicable(hop)) {
+            set_last_error("block-DFT path needs a power-of-two hop that divides every analysis window");
+            return PVQ_ERR_UNSUPPORTED;
+        }
+        use_block = true;
+    } else if (algo_ == PVQ_ALGO_AUTO) {
+        use_block = blockdft_applicable(hop) && total >= 64;
+    }
+    if (use_block && blockdft_takes_streams(hop)) {
+        std::vector<StreamIn> st;
+        st.reserve(n_streams);
+        for (uint32_t s = 0; s < n_streams; ++s)
+            if (n_frames[s] > 0) st.push_back(StreamIn{d_pcm[s], n_lead ? n_lead[s] : 0, n_frames[s], (size_t)s * stride});
+        return launch_blockdft_streams(st.data(), st.size(), hop, d_out_db, nullptr, rows_total, want_peaks ? &pk : nullptr, stream);
+    }
+    // one stream per call (the FFT path: any hop; the unfused block-DFT stages), the peaks once over all rows
+    for (uint32_t s = 0; s < n_streams; ++s) {
+        if (n_frames[s] == 0) continue;
+        float* out = d_out_db + (size_t)s * stride * nb;
+        pvq_status st = use_block ? launch_blockdft_path(d_pcm[s], n_lead ? n_lead[s] : 0, hop, n_frames[s], out, nullptr, nullptr, stream)
+                                  : launch_fft_path(d_pcm[s], n_lead ? n_lead[s] : 0, hop, n_frames[s], out, nullptr, nullptr, stream);
+        if (st != PVQ_OK) return st;
+    }
+    if (want_peaks) {
+        slot_begin(SLOT_PEAKS, stream);
+        pvq_status ps = launch_peaks_kernel(d_out_db, rows_total, pk, stream);
+        slot_end(SLOT_PEAKS, stream);
+        if (ps != PVQ_OK) return ps;
+        PVQ_HIP(hipGetLastError());
+    }
+    return PVQ_OK;
+}
+
 pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, size_t n_frames, float* out_db) {
     if (!has_device()) {
         set_last_error("handle was created without a device; there is no CPU fallback");

@@ -65,6 +65,13 @@ class Vqt {
     // device pointers, asynchronous on `stream`
     pvq_status calculate_batch_db_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
                                          float* d_out_db, float* d_out_cplx, hipStream_t stream);
+    // MANY streams in one call (the trainer's shape: many files side by side, pitchvis_train/src/train.rs:146-163; a stereo pair
+    // as two streams).  Stream s: d_pcm[s] holds n_lead[s] + n_frames[s] * hop samples; its frame f goes to output row
+    // s * out_stride_frames + f of d_out_db [n_streams][out_stride_frames][n_bins] and of the peak outputs; rows past a stream's
+    // n_frames are zero frames (no peaks).  On the block-DFT path all streams share each stage's launch.  pk may be null.
+    pvq_status batch_streams_device(const float* const* d_pcm, const size_t* n_lead, const size_t* n_frames, uint32_t n_streams, size_t hop,
+                                    float* d_out_db, size_t out_stride_frames, const AnalysisParameters* a, uint32_t* d_peak_mask,
+                                    uint32_t* d_peak_count, float* d_center, float* d_size, uint32_t max_peaks, hipStream_t stream);
     // the whole hot path, peaks fused into the frame kernels
     pvq_status vqt_analyze_batch_device(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
                                         const AnalysisParameters& a, float* d_out_db, uint32_t* d_peak_mask,
@@ -116,6 +123,10 @@ class Vqt {
     pvq_status launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
     bool blockdft_applicable(size_t hop) const;
+    bool blockdft_takes_streams(size_t hop);
+    struct StreamIn { const float* d_pcm; size_t n_lead, n_frames, out_row0; };   // one stream of a many-streams call: its frames go to output rows out_row0 ...
+    pvq_status launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t hop, float* d_out_db, float* d_out_cplx, size_t rows_total,
+                                       const PeakParamsDev* pk, hipStream_t stream);
     pvq_status prepare_blockdft(size_t hop);
     pvq_status launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames,
                                     float* d_out_db, float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
