@@ -260,10 +260,10 @@ def test_pipeline_pcm_to_analysis_on_device(hop, algo):
     for s in range(n_streams):
         x, _ = piano_roll(op.sr, seconds, 100 + s)
         pcm.append((x + white_noise(x.size, 200 + s, amp=0.01))[:nf * hop].astype(np.float32))
-    # stage 1 on the device: every stream's dB frames into ONE [stream][frame][bin] tensor (stage 2's input layout)
+    # stage 1 on the device: ONE many-streams call writes every stream's dB frames into the [stream][frame][bin] tensor stage 2 reads
     d_db = torch.empty((n_streams, nf, nb), device="cuda")
-    for s in range(n_streams):
-        v.calculate_batch_db_device(torch.from_numpy(pcm[s]).cuda(), hop, nf, d_db[s])
+    d_pcm = [torch.from_numpy(x).cuda() for x in pcm]
+    v.batch_streams_device(d_pcm, hop, [nf] * n_streams, d_db, nf)
     assert v.last_algo() == algo
     # stage 2 on the device, straight from d_db
     b = P.AnalysisBatch(pp.range, n_streams)

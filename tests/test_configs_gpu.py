@@ -64,14 +64,20 @@ def test_config4_96k_stereo_hop128(name):
     v = P.Vqt.new(pp, 0)
     ov = O.OracleVqt(op)
     hop, nf, n_lead = 128, 192, 40000
-    for seed in (0x5EED0004, 0x5EED0005):  # left, right
-        pcm = white_noise(n_lead + hop * nf, seed)
-        d_pcm = torch.from_numpy(pcm).cuda()
+    chans = [white_noise(n_lead + hop * nf, seed) for seed in (0x5EED0004, 0x5EED0005)]   # left, right
+    d_chans = [torch.from_numpy(c).cuda() for c in chans]
+    # the stereo pair as ONE many-streams call (pvq_vqt_calculate_batch_db_streams: both channels share every launch) ...
+    d_both = torch.empty((2, nf, v.n_bins), device="cuda")
+    v.batch_streams_device(d_chans, hop, [nf, nf], d_both, nf, n_leads=[n_lead, n_lead]); torch.cuda.synchronize()
+    assert v.last_algo() == P.ALGO_BLOCKDFT  # 256 hop blocks per 32768-sample window
+    for ch, (pcm, d_pcm) in enumerate(zip(chans, d_chans)):
+        # ... equals the single-stream call channel by channel (which also hands out the complex coefficients for the parity bars)
         d_db = torch.empty((nf, v.n_bins), device="cuda"); d_cx = torch.empty((nf, v.n_bins, 2), device="cuda")
         v.calculate_batch_db_device(d_pcm, hop, nf, d_db, n_lead=n_lead, d_out_cplx=d_cx); torch.cuda.synchronize()
-        assert v.last_algo() == P.ALGO_BLOCKDFT  # 256 hop blocks per 32768-sample window
+        assert v.last_algo() == P.ALGO_BLOCKDFT
+        assert torch.equal(d_both[ch], d_db)
         wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
-        assert_parity(d_db.cpu().numpy(), d_cx.cpu().numpy().view(np.complex64)[..., 0], wdb, wcx,
+        assert_parity(d_both[ch].cpu().numpy(), d_cx.cpu().numpy().view(np.complex64)[..., 0], wdb, wcx,
                       xpeak=input_peak(pcm, hop, nf, n_lead, v.window_union), sr=op.sr)
 
 
