@@ -62,6 +62,10 @@ struct BlockGroup {
     long long s_rel;  // window begin relative to the end of the n_fft buffer: w0 - n_fft
     int nb_f;       // blocks summed inside the fused kernel: min(nb, 64); the remaining levels run in blockdft_tree_finish
     int levels_f;   // log2(nb_f)
+    // general hops (a multiple of 64 that does not divide the window, blockdft_gemm_gen): window = nq whole hop blocks + rem samples
+    int nq, rem;
+    int e16r_off;   // float4 index of the group's slices of E16R (the DFT matrix of the first rem samples of a block)
+    int gtw_off;    // float2 index into gen_tw: phi (n_tiles * 32 columns), then tau
 };
 
 // 16 output bins (rows of one window group's kernel) and the contiguous range of X columns they read
@@ -125,13 +129,17 @@ struct BlockDftTables {
         const struct SegDev* d_segs = nullptr;
         const struct XTile* d_xmap = nullptr;
         std::vector<SegKey> key;                      // the runs the list was built for (stream geometry included: which tiles may pair up / take 16-byte loads)
-        int bm = 0, wide = 0, blocks = 0;
+        int bm = 0, wide = 0, blocks = 0, kind = 0;   // kind: 0 power-of-two hop (GEMM + tree); 1 / 2: R / Q tiles of a general hop
         bool multi = false;
         double eff_tiles = 0.0;                       // MFMA work of the list in whole 32-column tiles
+        double eff_flop = 0.0;                        // ... in flop (general hops: the depth differs by tile kind and group)
     } tile_lists[4];   // four slots: a batch's first, middle and last sub-batch alternate without rebuilding
     int tile_list_next = 0;
     unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch: 4 slots per sampled tile
     float4* d_E16 = nullptr;       // E in the B-operand order of the 16x16x4 GEMM: [column tile][k < hop / 2][n < 16]
+    bool general = false;          // the hop does not divide the windows: blockdft_gemm_gen (whole hop blocks + the window's remainder)
+    float4* d_E16R = nullptr;      // general hops: per group and column tile [k < rem / 2][n < 16]
+    float2* d_gen_tw = nullptr;    // general hops: per group phi, tau (n_tiles * 32 columns each)
 };
 
 void free_blockdft_tables(BlockDftTables* t) {
@@ -156,6 +164,8 @@ void free_blockdft_tables(BlockDftTables* t) {
         if (tl.d) (void)hipFree(tl.d);
     if (t->d_clk) (void)hipFree(t->d_clk);
     if (t->d_E16) (void)hipFree(t->d_E16);
+    if (t->d_E16R) (void)hipFree(t->d_E16R);
+    if (t->d_gen_tw) (void)hipFree(t->d_gen_tw);
     delete t;
 }
 
@@ -243,6 +253,10 @@ struct GemmTreeArgs {
     unsigned long long* stamps;   // developer knob PVQ_STAMPS: [workgroup][8] 100 MHz clock: 0 start, 1 after K loop, 2 after tree, 3 end, 4 all waves past the K loop, 5 P tile in LDS, 6 register levels done
     unsigned long long* clk;      // profiling only (pvq_vqt_set_profiling): every 64th workgroup stores (shader clock, 100 MHz clock) before and after its K loop
     const SegDev* segs;           // many-streams launches: the segment table (nullptr: one segment = the arguments above)
+    // general hops (blockdft_gemm_gen)
+    const float4* E16R;           // per group and column tile: [k < rem / 2][n < 16], as E16
+    const float2* gen_tw;         // per group: phi_c = e^{-2 pi i c hop / W} and tau_c (see the kernel), n_tiles * 32 columns each
+    int gen_kind;                 // 1: remainder tiles (R' -> Y, or -> X for windows shorter than the hop); 2: whole-block tiles (Q', combined, + tau R' -> X)
 };
 #define PVQ_STAMP(i) \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)stamp_slot * 8 + (i)] = wall_clock64();   // stamp_slot: the tile's (workgroup's) row of the dump
@@ -541,13 +555,15 @@ __device__ __forceinline__ void fused_f32_kloop(const Args& a, float* smem, long
 // E slice, (cos c_n, cos c_{n+16}, -sin c_n, -sin c_{n+16}) as one 16-byte LDS read.  Operands double-buffered, one k group ahead.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <int BM, bool HALF>   // tiles that lie wholly inside the stream (all but a handful per launch); HALF: at most 16 columns (a group's last tile): the second 16-column half is not computed
+// depth: samples of a row the DFT runs over (the hop; the general-hop kernel's second GEMM runs over the first `rem` samples of rows that
+// still lie a.K = hop samples apart)
 __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, long long tile_lo, const float4* e_tile, int tid,
-                                                  f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
+                                                  f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot, int depth) {
     constexpr int THREADS = 2 * BM;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(pcm_base);
     const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)pcm_bytes, 0x00020000};
-    const int K2 = a.K / 2;
+    const int K2 = depth / 2;
     const int nG = K2 / 32;   // (K2 is a multiple of 32: the fused path takes hops that are multiples of 64)
     // A load step fetches a DOUBLE k group (32 mirrored sample pairs): lane (row, kq) takes the 8 consecutive samples 32 G + 8 kq ...
     // of its row and the 8 mirrored ones, two 16-byte loads each, issued back to back — the four lanes of a row read one whole
@@ -562,7 +578,7 @@ __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, const f
     for (int mt = 0; mt < 2; ++mt) {
         const long long row_lo = tile_lo + (long long)(wave * 32 + mt * 16 + m16) * a.K;
         vf[mt] = (unsigned)((row_lo + 8 * kq) * 4ll);
-        vb[mt] = (unsigned)((row_lo + a.K - 8 - 8 * kq) * 4ll) - 128u * (unsigned)(nG - 1);
+        vb[mt] = (unsigned)((row_lo + depth - 8 - 8 * kq) * 4ll) - 128u * (unsigned)(nG - 1);
     }
     float fr[2][2][8], bk[2][2][8];
     // The prefetch is UNCONDITIONAL (the group index is clamped: past the last group the last one is fetched again into the idle
@@ -663,17 +679,17 @@ __device__ __forceinline__ void fused_f32_kloop16(const GemmTreeArgs& a, const f
 // per step inside the register budget.
 template <int BM>
 __device__ __forceinline__ void fused_f32_kloop16_edge(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, long long tile_lo, const float4* e_tile, int tid,
-                                                       f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
+                                                       f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot, int depth) {
     constexpr int THREADS = 2 * BM;
     const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm_base), 0, pcm_bytes, 0x00020000);
-    const int K2 = a.K / 2;
+    const int K2 = depth / 2;
     int jf0[2], jb0[2];   // sample indices relative to pcm_base (|.| < 2^30: the launch's stream is at most 4 GB)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row_lo = (int)tile_lo + (wave * 32 + mt * 16 + m16) * a.K;
         jf0[mt] = row_lo + 8 * kq;
-        jb0[mt] = row_lo + a.K - 4 - 8 * kq;
+        jb0[mt] = row_lo + depth - 4 - 8 * kq;
     }
     float fr[2][2][4], bk[2][2][4];
     auto load_group = [&](int buf, int g) {
@@ -870,11 +886,11 @@ __device__ __forceinline__ void fused_f32_narrow_tile(const GemmTreeArgs& a, con
     // a group's last column tile may hold 16 columns or fewer (3 of the 21 tiles at 48 kHz / 252 bins): half the MFMAs
     const bool half = T.ntl == T.G.n_tiles - 1 && T.G.n_cols - T.ntl * CB_C <= 16;
     if (!inside)
-        fused_f32_kloop16_edge<BM>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+        fused_f32_kloop16_edge<BM>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot, a.K);
     else if (half)
-        fused_f32_kloop16<BM, true>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+        fused_f32_kloop16<BM, true>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot, a.K);
     else
-        fused_f32_kloop16<BM, false>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+        fused_f32_kloop16<BM, false>(a, pcm_base, pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot, a.K);
     if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
         a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -961,6 +977,112 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
     // (the host pairs only tiles that lie inside the stream — same test, same numbers, launch(): the range-checked loop takes one tile)
     fused_f32_narrow_tile<BM>(a, ts.pcm_base, ts.pcm_bytes, smem, tw_lds[0], T, inside, tile_lo, tid, stamp_slot);
     PVQ_END_STAMPS
+}
+
+// ------------------------------------------------------------------------------------------------
+// General hops: a multiple of 64 samples that does NOT divide the windows (1 600 samples = 30 analyses per second at 48 kHz, the
+// cadence of pitchvis_serial/src/main.rs:41; the trainer's 3 x chunk, pitchvis_train/src/train.rs:43).  With W = nq hop + rem,
+//
+//     X_f[c] = sum_{q < nq} phi_c^q Q[f + q][c]  +  phi_c^nq R[f + nq][c],     phi_c = e^{-2 pi i c hop / W},
+//     Q[j][c] = sum_{m < hop} x[s + j hop + m] e^{-2 pi i c m / W}   (the whole hop block, as in the power-of-two case),
+//     R[j][c] = sum_{m < rem} x[s + j hop + m] e^{-2 pi i c m / W}   (the block's first rem samples),
+//
+// so every hop block is still transformed once (twice: whole and head) for all the frames that share it — the cost is per SAMPLE,
+// not per frame — and only the combine changes: nq <= 16 terms by Horner's rule instead of a power-of-two tree.  Both GEMMs are the
+// mirrored half-depth form about their block's centre (Q' = Q / rho_Q, R' = R / rho_R); rho_Q goes into the kernel-product
+// coefficients as before and tau_c = phi_c^nq rho_R / rho_Q multiplies R'.  Two launches of this kernel: the R tiles first (256 rows
+// = 256 frames, rows taken nq blocks further on, results to Y — or straight to X for a window shorter than the hop, nq = 0), then
+// the Q tiles (257 - nq frames per tile), which add tau Y on their way out.  Same K loop, same P tile, same X layout as
+// blockdft_gemm_tree: the kernel-product and peak stages do not know the difference.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_MAX_NQ = 16;   // whole blocks per window the combine takes (the P tile's 15 spare rows are its halo)
+template <int BM>
+__device__ __forceinline__ void gen_horner(float* smem, const float2* phi, int nq, int tid) {
+    float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);  // [BM + 15][33]
+    const int c = tid & (CB_C - 1), j0 = (tid >> 5) * 16;
+    const float2 w = phi[c];
+    float2 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = make_float2(0.0f, 0.0f);
+    // out[i] = v[i] + w (v[i + 1] + w (... + w v[i + nq - 1])): rows taken from the far end; row r feeds output i as term q = r - i
+    for (int r = 15 + nq - 1; r >= 0; --r) {
+        const float2 x = A[j0 + r][c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = r - i;
+            if (q >= 0 && q < nq) acc[i] = tree_cmadd(x, w, acc[i]);   // (uniform; the first term: x + w * 0 = x exactly)
+        }
+    }
+    __syncthreads();   // every thread has read its halo
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A[j0 + i][c] = acc[i];
+    __syncthreads();
+}
+
+template <int BM>
+__global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_gen(GemmTreeArgs a) {
+    constexpr int B_FLOATS = FR_KC * FT_BN;
+    constexpr int P_FLOATS = (BM + 15) * FT_LDP * 2;
+    __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice, then the P tile
+    __shared__ float2 gtw[2][CB_C];   // phi, tau of the tile's columns
+    const int tid = threadIdx.x;
+    const int4 entry = a.tile_list[blockIdx.x];   // .x: group | segment << 16
+    const TileStream ts = tile_stream(a, entry.x);
+    const BlockGroup G = a.gv[entry.x & 7];
+    const int ntl = entry.y, f0 = entry.z, nt = G.tile0 + ntl;
+    if (f0 >= ts.n_frames) return;
+    const int stamp_slot = blockIdx.x;
+    const bool is_r = a.gen_kind == 1;
+    const int depth = is_r ? G.rem : a.K;
+    // rows of the tile: hop blocks f0 .. f0 + BM - 1 of the group's block grid (R tiles: nq blocks further on)
+    const long long tile_lo = ts.base + G.s_rel + (long long)(f0 + (is_r ? G.nq : 0)) * a.K;
+    const long long tile_hi = tile_lo + (long long)(BM - 1) * a.K + depth;
+    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)ts.pcm_bytes;
+    const float4* e_tile = is_r ? a.E16R + G.e16r_off + (size_t)ntl * (G.rem / 2) * 16 : a.E16 + (size_t)nt * (a.K / 2) * 16;
+    if (tid < 2 * CB_C) gtw[tid >> 5][tid & (CB_C - 1)] = a.gen_tw[G.gtw_off + (tid >> 5) * (G.n_tiles * CB_C) + ntl * CB_C + (tid & (CB_C - 1))];
+    f32x4a accR[2][2], accI[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accR[mt][np][r] = 0.0f;
+                accI[mt][np][r] = 0.0f;
+            }
+    const bool half = ntl == G.n_tiles - 1 && G.n_cols - ntl * CB_C <= 16;
+    float* no_tw = reinterpret_cast<float*>(&gtw[0][0]);   // (no tree twiddles to stage: tw_levels = 0)
+    if (!inside)
+        fused_f32_kloop16_edge<BM>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, no_tw, no_tw, 0, 0, stamp_slot, depth);
+    else if (half)
+        fused_f32_kloop16<BM, true>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, no_tw, no_tw, 0, 0, stamp_slot, depth);
+    else
+        fused_f32_kloop16<BM, false>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, no_tw, no_tw, 0, 0, stamp_slot, depth);
+    __syncthreads();   // the E slice is dead: the P' tile takes its place
+    fused_dump_p<BM, 2, 0>(smem, accR, accI, tid);
+    __syncthreads();
+    if (!is_r && G.nq > 1) gen_horner<BM>(smem, gtw[0], G.nq, tid);
+    // store: lanes walk the frames of one column (512-byte runs); Q tiles add tau * R'[f + nq] (the R launch left it in Y)
+    float2 (*A)[FT_LDP] = reinterpret_cast<float2 (*)[FT_LDP]>(smem);
+    const int j = tid % BM;
+    const int f = f0 + j;
+    const int S = is_r ? BM : BM - (G.nq > 1 ? G.nq - 1 : 0);
+    if (j < S && f < ts.n_frames) {
+        const size_t at = ((size_t)((f >> 6) + ts.xt0) * a.xcp + nt * CB_C) * 64 + (f & 63);
+        float2* dst = (is_r && G.nq > 0 ? a.Y : a.X) + at;
+        const float2* ysrc = a.Y + at;
+        const bool add_y = !is_r && G.rem > 0;
+        const int ncv = G.n_cols - ntl * CB_C < CB_C ? G.n_cols - ntl * CB_C : CB_C;
+#pragma unroll 4
+        for (int cc = tid / BM; cc < ncv; cc += 2) {
+            float2 val = A[j][cc];
+            if (add_y) val = tree_cmadd(val, gtw[1][cc], ysrc[cc * 64]);
+            if (is_r && G.nq > 0)
+                dst[cc * 64] = val;   // read back by the Q launch: through the L2
+            else
+                __builtin_nontemporal_store((f32x2){val.x, val.y}, reinterpret_cast<f32x2*>(&dst[cc * 64]));
+        }
+    }
 }
 
 // Unfused form of the same GEMM (windows of more than 64 hop blocks: the tree runs as its own kernel over P' in memory):
@@ -1864,17 +1986,27 @@ uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_
 bool Vqt::blockdft_takes_streams(size_t hop) {
     if (!blockdft_applicable(hop) || prepare_blockdft(hop) != PVQ_OK) return false;
     const BlockDftTables* t = dev_->block;
+    if (t->general) return true;
     const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
     return !dev_knob("PVQ_NO_FUSE", 0) && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
 }
 
 bool Vqt::blockdft_applicable(size_t hop) const {
-    if (!has_device() || hop < 64 || (hop & (hop - 1)) != 0 || hop > 4096) return false;   // the mirrored K loop walks hop / 2 in stages of 32
+    if (!has_device() || hop < 64 || hop % 64 != 0 || hop > 4096) return false;   // the mirrored K loop walks hop / 2 in stages of 32
     if (n_bins() > 1024) return false;
+    bool divides = (hop & (hop - 1)) == 0;
+    for (const WindowGroup& g : plan_.kernel.window_groups) divides = divides && g.window_size() % hop == 0;
+    if (divides) {   // power-of-two hop dividing every window: hop-block GEMM + doubling tree
+        for (const WindowGroup& g : plan_.kernel.window_groups)
+            if (g.window_size() / hop > (size_t)CB_MAX_NB) return false;
+        return true;
+    }
+    // general hop (a multiple of 64): whole hop blocks + the window's remainder, combined by Horner's rule over at most GEN_MAX_NQ blocks;
+    // the fused kernel only (at most 8 window groups), windows a multiple of 64 samples
+    if (plan_.kernel.window_groups.size() > 8) return false;
     for (const WindowGroup& g : plan_.kernel.window_groups) {
         const size_t ws = g.window_size();
-        if (ws % hop != 0) return false;
-        if (ws / hop > (size_t)CB_MAX_NB) return false;
+        if (ws % 64 != 0 || ws / hop > (size_t)GEN_MAX_NQ) return false;
     }
     return true;
 }
@@ -1913,18 +2045,35 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                 col_of[g].push_back(c);
             }
     }
+    {
+        bool divides = (hop & (hop - 1)) == 0;
+        for (const WindowGroup& g : groups) divides = divides && g.window_size() % hop == 0;
+        t->general = !divides;
+    }
+    int e16r_off = 0, gtw_off = 0;
     for (size_t g = 0; g < groups.size(); ++g) {
         BlockGroup B{};
-        B.nb = (int)(groups[g].window_size() / hop);
-        B.levels = 0;
-        while ((1 << B.levels) < B.nb) ++B.levels;
-        B.nb_f = std::min(B.nb, 64);
-        B.levels_f = std::min(B.levels, 6);
+        if (t->general) {   // window = nq whole hop blocks + rem samples; no tree
+            B.nq = (int)(groups[g].window_size() / hop);
+            B.rem = (int)(groups[g].window_size() % hop);
+            B.nb = B.nb_f = 1;
+            B.levels = B.levels_f = 0;
+        } else {
+            B.nb = (int)(groups[g].window_size() / hop);
+            B.levels = 0;
+            while ((1 << B.levels) < B.nb) ++B.levels;
+            B.nb_f = std::min(B.nb, 64);
+            B.levels_f = std::min(B.levels, 6);
+        }
         B.n_cols = (int)col_of[g].size();
         B.tile0 = tile;
         B.n_tiles = (B.n_cols + CB_C - 1) / CB_C;
         B.tw_off = tw_off;
         B.s_rel = (long long)groups[g].window_begin - (long long)plan_.params.n_fft;  // + n_lead + hop at launch
+        B.e16r_off = e16r_off;
+        B.gtw_off = gtw_off;
+        e16r_off += B.n_tiles * (B.rem / 2) * 16;
+        gtw_off += 2 * B.n_tiles * CB_C;
         tile += B.n_tiles;
         tw_off += B.levels * B.n_tiles * CB_C;
         t->nb_max = std::max(t->nb_max, B.nb);
@@ -1949,8 +2098,10 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
         rho[g].resize(B.n_cols);
         for (int ci = 0; ci < B.n_cols; ++ci) {
             const long long c = (long long)col_of[g][ci];  // actual spectrum column
-            {
-                const long long prod = (c * (long long)(hop - 1)) % W2;
+            {   // the phase of the centred block DFT whose results the kernel product sees: the hop block's, or — a window shorter than a
+                // general hop, where the transform is the remainder GEMM alone — the window's
+                const long long D = t->general && B.nq == 0 ? (long long)B.rem : (long long)hop;
+                const long long prod = (c * (D - 1)) % W2;
                 const double ang = -2.0 * pi * (double)prod / (double)W2;
                 rho[g][ci] = {std::cos(ang), std::sin(ang)};
             }
@@ -2203,8 +2354,35 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
                     E16[((size_t)tt * K2 + m) * 16 + n] = make_float4(e[2 * n], e[2 * (n + 16)], e[2 * n + 1], e[2 * (n + 16) + 1]);
                 }
     }
+    std::vector<float4> E16R((size_t)std::max(e16r_off, 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    std::vector<float2> gen_tw((size_t)std::max(gtw_off, 1), make_float2(1.0f, 0.0f));
+    if (t->general) {
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const BlockGroup& B = t->groups[g];
+            const long long W = (long long)groups[g].window_size(), W2 = 2 * W;
+            auto cs = [&](long long num, long long den) {   // e^{-2 pi i num / den}, the angle reduced exactly
+                long long r = num % den;
+                if (r < 0) r += den;
+                const double ang = -2.0 * pi * (double)r / (double)den;
+                return make_float2(tq(std::cos(ang)), tq(std::sin(ang)));
+            };
+            for (int ci = 0; ci < B.n_cols; ++ci) {
+                const long long c = (long long)col_of[g][ci];
+                const int tt = ci / CB_C, n32 = ci % CB_C;
+                // E_R[m][c] = e^{-i th_c (m - (rem - 1) / 2)}, m < rem / 2 (the mirrored form reads the first half), B-operand order of E16
+                for (int m = 0; m < B.rem / 2; ++m) {
+                    const float2 e = cs(c * (2ll * m - (long long)B.rem + 1ll), W2);
+                    float4& dst = E16R[(size_t)B.e16r_off + ((size_t)tt * (B.rem / 2) + m) * 16 + (n32 & 15)];
+                    if (n32 < 16) { dst.x = e.x; dst.z = e.y; } else { dst.y = e.x; dst.w = e.y; }
+                }
+                // phi_c = e^{-2 pi i c hop / W};  tau_c = phi_c^nq rho_R / rho_Q = e^{-i th_c (nq hop + (rem - hop) / 2)}
+                gen_tw[(size_t)B.gtw_off + ci] = cs(c * (long long)hop, W);
+                gen_tw[(size_t)B.gtw_off + B.n_tiles * CB_C + ci] = B.nq > 0 ? cs(c * (2ll * B.nq * (long long)hop + (long long)B.rem - (long long)hop), W2) : make_float2(1.0f, 0.0f);
+            }
+        }
+    }
     t->h_E = E;  // kept for the lazily built bf16 planes
-    bool ok = up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
+    bool ok = up(&t->d_E16R, E16R) && up(&t->d_gen_tw, gen_tw) && up(&t->d_E, E) && up(&t->d_tile_group, tile_group) && up(&t->d_tile_s, tile_s) && up(&t->d_groups, t->groups) &&
               up(&t->d_comb_tw, comb_tw) && up(&t->d_band, band) && up(&t->d_band_B, band_B) && up(&t->d_band_list, band_list) && up(&t->d_band8, band8) &&
               up(&t->d_band_B4, band_B4) && up(&t->d_band_list8, band_list8) &&
               up(reinterpret_cast<uint16_t**>(&t->d_band_B3), band_B3) &&
@@ -2247,9 +2425,9 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
     }
     const size_t chunk = std::min(n_st == 1 ? longest : std::max<size_t>((total_frames + 63) / 64 * 64, 64),
                                   chunk_frames(workspace_limit_, (size_t)xcp * sizeof(float2) * (t->nb_max > 64 ? 2 : 1)));
-    const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
+    const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0 && !t->general;   // (a general hop runs the fp32 GEMM whatever the setting; the kernel product follows the setting)
     static const bool fuse_env = !dev_knob("PVQ_NO_FUSE", 0);
-    const bool fused = fuse_env && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
+    const bool fused = t->general || (fuse_env && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0);
     if (!fused && n_st > 1) {
         set_last_error("internal: the unfused block-DFT stages take one stream per call");
         return PVQ_ERR_INTERNAL;
@@ -2295,7 +2473,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
         PVQ_HIP(hipMemsetAsync(t->d_X, 0, x_bytes, stream));
         t->x_cap = x_bytes;
     }
-    if (fused && t->nb_max > 64) {
+    if (fused && (t->nb_max > 64 || t->general)) {   // (general hops: the remainder GEMM's results, laid out like X)
         const size_t y_bytes = y_tiles * (size_t)xcp * 64 * sizeof(float2);
         if (t->y_cap < y_bytes) {
             if (t->d_Y) PVQ_HIP(hipFree(t->d_Y));
@@ -2403,7 +2581,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             static const int pair_half_env = dev_knob("PVQ_PAIR_HALF", 0); // 1: a group's last tile of at most 16 columns pairs up too (measured: same time, more MFMAs)
             static const int tail_env = dev_knob("PVQ_TAIL", 128);       // narrow entries at the end of every queue
             static const int wide_env = dev_knob("PVQ_WIDE", 1);         // 0: narrow tiles only; 2: wide tiles to the very end of every queue; 3: none in a queue's last stripe
-            const int wide_mode = !use_bf && fused_bm == 256 ? wide_env : 0;   // (the split-bf16 kernel and the 128-row form take 32-column tiles only)
+            const int wide_mode = !use_bf && fused_bm == 256 && !t->general ? wide_env : 0;   // (the split-bf16 kernel, the 128-row form and the general-hop kernel take 32-column tiles only)
             if (segs.size() > 0xFFFFu) {
                 set_last_error("too many streams in one launch");
                 return PVQ_ERR_INTERNAL;
@@ -2415,9 +2593,11 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             // so the middle sub-batches of a long stream share one list, and so do different buffers of one geometry)
             std::vector<BlockDftTables::SegKey> key = segs;
             if (!multi) key[0].pcm_off = key[0].out_row0 = 0;
-            BlockDftTables::TileList* tl = nullptr;
+            // kind 0: the tiles of a power-of-two hop (GEMM + tree); 1 / 2: the remainder / whole-block tiles of a general hop
+            auto get_list = [&](int kind, BlockDftTables::TileList*& tl) -> pvq_status {
+            tl = nullptr;
             for (auto& c : t->tile_lists)
-                if (c.bm == fused_bm && c.wide == wide_mode && c.multi == multi && c.key == key) tl = &c;
+                if (c.bm == fused_bm && c.wide == wide_mode && c.multi == multi && c.kind == kind && c.key == key) tl = &c;
             if (!tl) {
                 tl = &t->tile_lists[t->tile_list_next];
                 t->tile_list_next = (t->tile_list_next + 1) & 3;
@@ -2426,15 +2606,22 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 auto seg_of = [](const int4& e) { return (int)((unsigned)e.x >> 16); };
                 auto inside_of = [&](int g, int seg, int f0) {   // the kernel's own test
                     const BlockGroup& G = t->groups[g];
-                    const long long tile_lo = segs[seg].base + G.s_rel + (long long)f0 * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
+                    if (kind == 0) {
+                        const long long tile_lo = segs[seg].base + G.s_rel + (long long)f0 * (long long)hop, tile_hi = tile_lo + (long long)fused_bm * (long long)hop;
+                        return tile_lo >= 0 && tile_hi * 4ll <= (long long)segs[seg].pcm_bytes;
+                    }
+                    const long long depth = kind == 1 ? G.rem : (long long)hop;
+                    const long long tile_lo = segs[seg].base + G.s_rel + (long long)(f0 + (kind == 1 ? G.nq : 0)) * (long long)hop;
+                    const long long tile_hi = tile_lo + (long long)(fused_bm - 1) * (long long)hop + depth;
                     return tile_lo >= 0 && tile_hi * 4ll <= (long long)segs[seg].pcm_bytes;
                 };
                 std::vector<std::vector<int4>> q(8);
                 for (size_t u = 0; u < segs.size(); ++u)
                     for (int g = 0; g < t->n_groups; ++g) {
                         const BlockGroup& G = t->groups[g];
-                        const int S = fused_bm - G.nb_f + 1;
-                        const int rows_g = segs[u].nf + G.nb - G.nb_f;
+                        if ((kind == 1 && G.rem == 0) || (kind == 2 && G.nq == 0)) continue;
+                        const int S = kind == 0 ? fused_bm - G.nb_f + 1 : kind == 1 ? fused_bm : fused_bm - (G.nq > 1 ? G.nq - 1 : 0);
+                        const int rows_g = kind == 0 ? segs[u].nf + G.nb - G.nb_f : segs[u].nf;
                         const bool half_last = G.n_cols - (G.n_tiles - 1) * CB_C <= 16;
                         for (int f0 = 0; f0 < rows_g; f0 += S)
                             for (int ntl = 0; ntl < G.n_tiles; ++ntl) {
@@ -2451,6 +2638,10 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 auto tile_cost = [&](const int4& e) {
                     const BlockGroup& G = t->groups[grp(e)];
                     const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
+                    if (kind != 0) {   // a general hop's tiles: the K loop's depth decides
+                        const int depth = kind == 1 ? G.rem : (int)hop;
+                        return (inside_of(grp(e), seg_of(e), e.z) ? (half ? 1 : 2) : 4) * (depth / 32) + 8 + (kind == 2 ? G.nq : 0);
+                    }
                     if (!inside_of(grp(e), seg_of(e), e.z)) return 2 * 16 + G.levels_f;   // the range-checked loop: dword loads
                     return ((half ? 8 : 16) + G.levels_f) * (is_wide(e) ? 2 : 1);
                 };
@@ -2514,11 +2705,14 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                     Lq = std::max(Lq, v.size());
                 }
                 tl->eff_tiles = 0.0;
+                tl->eff_flop = 0.0;
                 for (auto& v : q)
                     for (const int4& e : v) {
                         const BlockGroup& G = t->groups[grp(e)];
                         const bool half = e.y == G.n_tiles - 1 && G.n_cols - e.y * CB_C <= 16;
-                        tl->eff_tiles += is_wide(e) ? 2.0 : (half ? 0.5 : 1.0);   // (the few range-checked tiles run the full loop: counted as half all the same)
+                        const double et = is_wide(e) ? 2.0 : (half ? 0.5 : 1.0);   // (the few range-checked tiles run the full loop: counted as half all the same)
+                        tl->eff_tiles += et;
+                        tl->eff_flop += et * fused_bm * (2 * CB_C) * ((kind == 1 ? (double)G.rem : (double)hop) / 2) * 2.0;   // (mirrored fp32 form: half depth)
                     }
                 std::vector<int4> list(8 * std::max<size_t>(Lq, 1), make_int4(0, 0, 0x3FFFFFFF, 0));   // padding entries: past every group's rows
                 for (int x = 0; x < 8; ++x) {
@@ -2554,7 +2748,24 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 tl->bm = fused_bm;
                 tl->wide = wide_mode;
                 tl->multi = multi;
+                tl->kind = kind;
                 tl->blocks = (int)list.size();
+            }
+            return PVQ_OK;
+            };   // get_list
+            BlockDftTables::TileList* tl = nullptr;
+            BlockDftTables::TileList* tl_r = nullptr;
+            if (t->general) {
+                pvq_status ls = get_list(1, tl_r);
+                if (ls != PVQ_OK) return ls;
+                ls = get_list(2, tl);
+                if (ls != PVQ_OK) return ls;
+                // (the second lookup may have evicted the first: four slots, two lists per launch shape — look it up again)
+                ls = get_list(1, tl_r);
+                if (ls != PVQ_OK) return ls;
+            } else {
+                pvq_status ls = get_list(0, tl);
+                if (ls != PVQ_OK) return ls;
             }
             fa.tile_list = tl->d;
             d_segs = multi ? tl->d_segs : nullptr;
@@ -2577,6 +2788,9 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             // (depth hop / 2 in the mirrored fp32 form, hop in the split-bf16 form, where it counts fp32-equivalent products)
             if (!use_bf) eff_tiles = tl->eff_tiles;   // (what the list's entries issue: a wide entry two whole tiles, a lone half tile half a tile)
             last_gemm_flop_ = eff_tiles * fused_bm * (2 * CB_C) * (use_bf ? (double)hop : (double)hop / 2) * 2.0;
+            fa.E16R = t->d_E16R;
+            fa.gen_tw = t->d_gen_tw;
+            fa.gen_kind = 0;
             fa.clk = nullptr;
             if (profiling_ && !use_bf) {
                 const size_t need = ((size_t)off / 64 + 1) * 4 * sizeof(unsigned long long);
@@ -2591,7 +2805,24 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 fa.clk = t->d_clk;
             }
             slot_begin(SLOT_BLOCKDFT_GEMM, stream);
-            if (use_bf)
+            if (t->general) {
+                // the remainder tiles first (their results wait in Y), then the whole-block tiles; flop: both launches' K loops
+                double flop = 0.0;
+                for (int kind = 1; kind <= 2; ++kind) {
+                    const BlockDftTables::TileList* L = kind == 1 ? tl_r : tl;
+                    if (L->blocks == 0 || L->eff_tiles == 0.0) continue;
+                    GemmTreeArgs ga = fa;
+                    ga.tile_list = L->d;
+                    ga.segs = multi ? L->d_segs : nullptr;
+                    ga.gen_kind = kind;
+                    ga.stamps = nullptr;
+                    ga.clk = nullptr;
+                    hipLaunchKernelGGL(blockdft_gemm_gen<256>, dim3(L->blocks), dim3(512), 0, stream, ga);
+                    flop += L->eff_flop;
+                }
+                last_gemm_flop_ = flop;
+                d_xmap = multi ? tl->d_xmap : nullptr;
+            } else if (use_bf)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
