@@ -152,7 +152,12 @@ pvq_status pvq_vqt_input_status(pvq_vqt *v, void *stream);
 typedef enum pvq_algo {
     PVQ_ALGO_AUTO = 0,
     PVQ_ALGO_FFT = 1,      /* per-frame LDS FFT per window group (any hop) */
-    PVQ_ALGO_BLOCKDFT = 2  /* hop-block DFT on fp32 MFMA + phase combine (power-of-two hop dividing every window) */
+    PVQ_ALGO_BLOCKDFT = 2  /* hop-block DFT on fp32 MFMA + phase combine: every hop block is transformed once for all the frames that
+                            * share it.  Takes a power-of-two hop (>= 64) that divides every window (doubling tree); a multiple of 64 that
+                            * the longest window holds at most 16 times, e.g. 1 600 (whole blocks + the window's remainder, Horner combine);
+                            * or a hop whose 2-, 4-, 8- or 16-fold is one of those, e.g. 800 or 320 (that many interleaved block grids).
+                            * PVQ_ALGO_AUTO picks it whenever it applies and the batch has >= 64 frames per grid; forcing it on another hop
+                            * (735, say) returns PVQ_ERR_UNSUPPORTED */
 } pvq_algo;
 pvq_status pvq_vqt_set_algo(pvq_vqt *v, pvq_algo algo);
 /* which algorithm the last batch call actually used */

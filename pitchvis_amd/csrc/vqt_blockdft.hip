@@ -119,9 +119,10 @@ struct BlockDftTables {
     struct SegKey {   // one run of a launch: what decides its tiles, where its frames go
         long long pcm_off, base, out_row0;
         unsigned pcm_bytes;
-        int nf, x_tile0, y_tile0;
+        int nf, x_tile0, y_tile0, row_step;
         bool operator==(const SegKey& o) const {
-            return pcm_off == o.pcm_off && base == o.base && out_row0 == o.out_row0 && pcm_bytes == o.pcm_bytes && nf == o.nf && x_tile0 == o.x_tile0 && y_tile0 == o.y_tile0;
+            return pcm_off == o.pcm_off && base == o.base && out_row0 == o.out_row0 && pcm_bytes == o.pcm_bytes && nf == o.nf && x_tile0 == o.x_tile0 && y_tile0 == o.y_tile0 &&
+                   row_step == o.row_step;
         }
     };
     struct TileList {
@@ -228,7 +229,8 @@ struct alignas(16) SegDev {
 };
 struct XTile {
     long long out_row0;   // output row (of out_db, masks, ...) of the tile's frame 0
-    int n_live;           // frames of the tile that exist
+    int live_step;        // bits 0..7: frames of the tile that exist (<= 64); bits 8..: output rows between consecutive frames (1, or r
+                          // for a run that holds every r-th frame of its stream: Vqt::run_batch's interleaved block grids)
     int y_tile;           // the Y tile that holds the same frames' 64-block partial sums
 };
 
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(256) void blockdft_tree_finish(FinishArgs a) {
     int ytile = tile, n_live = a.n_frames - tile * 64;
     if (a.xmap) {
         ytile = a.xmap[tile].y_tile;
-        n_live = a.xmap[tile].n_live;
+        n_live = a.xmap[tile].live_step & 255;
     }
     if (cc >= a.n_real || fr >= n_live) return;
     const int col = a.col0 + cc;
@@ -1468,7 +1470,7 @@ __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 constexpr int BAND_LDB2 = 260;   // the 64-frame form: up to 256 bins + 4 (rows 4 apart land 16 banks apart)
 constexpr int BAND_LDB3 = 308;   // the 64-frame 8-bin form up to 304 bins (78.8 KB: still two workgroups per CU)
 template <int MT, int LDB>
-__device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, long long row0, int n_live, int bin0, int nrows,
+__device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* dbs, const BandArgs& a, long long row0, int n_live, int rstep, int bin0, int nrows,
                                               int lane) {
     const int ldb = LDB ? LDB : a.ldb;
     const int n = lane & 31, kx = lane >> 5;
@@ -1496,7 +1498,7 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int fr = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * kx;
-                    if (fr < n_live) a.out_cplx[(size_t)(row0 + fr) * row_stride + bin] = make_float2(acc[mt][q], im[q]);
+                    if (fr < n_live) a.out_cplx[(size_t)(row0 + (long long)fr * rstep) * row_stride + bin] = make_float2(acc[mt][q], im[q]);
                 }
             }
         }
@@ -1507,7 +1509,7 @@ __device__ __forceinline__ void band_writeout(const f32x16 (&acc)[MT], float* db
 // time with their dB values in registers, so the read -> log -> reduce -> rescale chains of the frames overlap
 // (the phase is latency-bound at two waves per SIMD); more bins: one frame at a time through LDS.
 template <int MT, int NW, int LDB = (MT == 2 ? BAND_LDB2 : 0)>
-__device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, long long row0, int n_live, int wave, int lane) {
+__device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, long long row0, int n_live, int rstep, int wave, int lane) {
     const int ldb = LDB ? LDB : a.ldb;
     const float ref_db = 10.0f * log10f(PVQ_REF_POWER);
     // 10 log10(p) = 10 log10(2) * log2(p) on the hardware log2 (1 ulp): within 2e-5 dB of the libm route
@@ -1549,7 +1551,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, long 
                 if (fr >= n_live) continue;
                 const float floor_db = mx[u] - PVQ_TOP_DB;
                 const float m2 = fmaxf(mn[u], floor_db);
-                float* dst = a.out_db + (size_t)(row0 + fr) * a.n_bins;
+                float* dst = a.out_db + (size_t)(row0 + (long long)fr * rstep) * a.n_bins;
 #pragma unroll
                 for (int kk = 0; kk < NKB; ++kk) {
                     const int k = lane + 64 * kk;
@@ -1584,7 +1586,7 @@ __device__ __forceinline__ void band_finish(float* dbs, const BandArgs& a, long 
         mn = wave_min(mn);
         const float floor_db = mx - PVQ_TOP_DB;
         const float m2 = fmaxf(mn, floor_db);
-        float* dst = a.out_db + (size_t)(row0 + fr) * a.n_bins;
+        float* dst = a.out_db + (size_t)(row0 + (long long)fr * rstep) * a.n_bins;
         for (int k = lane; k < a.n_bins; k += 64) {
             const float c = fmaxf(rowp[k], floor_db);
             dst[k] = (m2 > 0.0f) ? (c - m2) : fmaxf(c, 0.0f);
@@ -1604,11 +1606,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
     // the output rows of this workgroup's frames: rows f0 ... of a single stream, or what the X tile's entry of the map says
     long long row0 = f0;
-    int n_live = a.n_frames - f0;
+    int n_live = a.n_frames - f0, rstep = 1;
     if (a.xmap) {   // (uniform)
         const XTile xt = a.xmap[f0 >> 6];
-        row0 = xt.out_row0 + (f0 & 63);
-        n_live = xt.n_live - (f0 & 63);
+        rstep = xt.live_step >> 8;
+        row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
+        n_live = (xt.live_step & 255) - (f0 & 63);
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -1687,12 +1690,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
             blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
             open_block(blk);
         }
-        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, row0, n_live, bin0, nrows, lane);
+        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, row0, n_live, rstep, bin0, nrows, lane);
     }
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<MT, NW>(dbs, a, row0, n_live, wave, lane);
+    band_finish<MT, NW>(dbs, a, row0, n_live, rstep, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1723,11 +1726,12 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // (a half-tile workgroup starts at frame pair 16 of its tile)
     // the output rows of this workgroup's frames: rows f0 ... of a single stream, or what the X tile's entry of the map says
     long long row0 = f0;
-    int n_live = a.n_frames - f0;
+    int n_live = a.n_frames - f0, rstep = 1;
     if (a.xmap) {   // (uniform)
         const XTile xt = a.xmap[f0 >> 6];
-        row0 = xt.out_row0 + (f0 & 63);
-        n_live = xt.n_live - (f0 & 63);
+        rstep = xt.live_step >> 8;
+        row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
+        n_live = (xt.live_step & 255) - (f0 & 63);
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -1812,7 +1816,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int fr = 32 * u + 8 * kq + 2 * q + p;
-                            if (fr < n_live) a.out_cplx[(size_t)(row0 + fr) * row_stride + bin] = make_float2(acc[u][p][q], im[q]);
+                            if (fr < n_live) a.out_cplx[(size_t)(row0 + (long long)fr * rstep) * row_stride + bin] = make_float2(acc[u][p][q], im[q]);
                         }
                     }
                 }
@@ -1821,7 +1825,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<NU, NW, LDB>(dbs, a, row0, n_live, wave, lane);
+    band_finish<NU, NW, LDB>(dbs, a, row0, n_live, rstep, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -1848,11 +1852,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
     const float* xtile = a.X + ((size_t)(f0 >> 6) * a.xcp) * col_stride + (f0 & 63) * 2;   // this workgroup's frames
     // the output rows of this workgroup's frames: rows f0 ... of a single stream, or what the X tile's entry of the map says
     long long row0 = f0;
-    int n_live = a.n_frames - f0;
+    int n_live = a.n_frames - f0, rstep = 1;
     if (a.xmap) {   // (uniform)
         const XTile xt = a.xmap[f0 >> 6];
-        row0 = xt.out_row0 + (f0 & 63);
-        n_live = xt.n_live - (f0 & 63);
+        rstep = xt.live_step >> 8;
+        row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
+        n_live = (xt.live_step & 255) - (f0 & 63);
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -1932,12 +1937,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
             blk = a.blocks[__builtin_amdgcn_readfirstlane(my_list[bi + 2])];
             open_block(blk);
         }
-        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, row0, n_live, bin0, nrows, lane);
+        band_writeout<MT, MT == 2 ? BAND_LDB2 : 0>(acc, dbs, a, row0, n_live, rstep, bin0, nrows, lane);
     }
     PVQ_STAMP(1);
     __syncthreads();
     PVQ_STAMP(2);
-    band_finish<MT, NW>(dbs, a, row0, n_live, wave, lane);
+    band_finish<MT, NW>(dbs, a, row0, n_live, rstep, wave, lane);
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -2401,7 +2406,7 @@ pvq_status Vqt::prepare_blockdft(size_t hop) {
 // the streams contend for the same CUs.)
 pvq_status Vqt::launch_blockdft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                      float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
-    const StreamIn one{d_pcm, n_lead, n_frames, 0};
+    const StreamIn one{d_pcm, n_lead + hop, n_lead + n_frames * hop, n_frames, 0, 1};
     return launch_blockdft_streams(&one, 1, hop, d_out_db, d_out_cplx, n_frames, pk, stream);
 }
 
@@ -2515,29 +2520,32 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
         if (st[i].d_pcm < pcm_min) pcm_min = st[i].d_pcm;
     for (const auto& L : launches) {
         // per run: rebase its stream so that every byte offset of the launch fits 32 bits
-        const bool multi = L.size() > 1;
+        bool strided = false;   // a run that holds every r-th frame of its stream: its rows go through the X-tile map too
         std::vector<BlockDftTables::SegKey> segs(L.size());
         size_t xt_n = 0, yt_n = 0, nf_launch = 0;
         for (size_t u = 0; u < L.size(); ++u) {
             const Run& r = L[u];
             const StreamIn& S = st[r.stream];
-            const long long n_samples = (long long)(S.n_lead + S.n_frames * hop);
-            const long long first_needed = (long long)S.n_lead + (long long)hop + (long long)r.fbeg * (long long)hop - (long long)plan_.params.n_fft;
+            const long long n_samples = (long long)S.n_samples;
+            const long long first_needed = (long long)S.first_end + (long long)r.fbeg * (long long)hop - (long long)plan_.params.n_fft;
             const long long rebase = std::max<long long>(0, std::min<long long>(first_needed, n_samples));
             const long long extent = std::min<long long>(n_samples - rebase, (long long)(r.nf + 2) * (long long)hop + (long long)plan_.params.n_fft + 4096);
             BlockDftTables::SegKey& k = segs[u];
             k.pcm_off = (long long)(S.d_pcm - pcm_min) + rebase;
             k.pcm_bytes = (unsigned)std::min<long long>(extent * 4, 0xFFFFF000ll);
-            k.base = (long long)S.n_lead + (long long)hop + (long long)r.fbeg * (long long)hop - rebase;
+            k.base = (long long)S.first_end + (long long)r.fbeg * (long long)hop - rebase;
             k.nf = (int)r.nf;
             k.x_tile0 = (int)xt_n;
             k.y_tile0 = (int)yt_n;
-            k.out_row0 = (long long)(S.out_row0 + r.fbeg);
+            k.out_row0 = (long long)(S.out_row0 + r.fbeg * S.row_step);
+            k.row_step = (int)S.row_step;
+            strided |= S.row_step != 1;
             xt_n += (r.nf + 63) / 64;
             yt_n += (r.nf + (size_t)std::max(t->nb_max - 64, 0) + 63) / 64;
             nf_launch += r.nf;
         }
         // a launch of one run goes through the kernel arguments (segs == nullptr), as the single-stream entry point always did
+        const bool multi = L.size() > 1 || strided;
         const float* pcm_base = multi ? pcm_min : pcm_min + segs[0].pcm_off;
         const unsigned pcm_bytes = segs[0].pcm_bytes;
         const long long base = segs[0].base;
@@ -2728,7 +2736,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                     hsegs[u] = SegDev{segs[u].pcm_off, segs[u].base, segs[u].pcm_bytes, segs[u].nf, segs[u].x_tile0, segs[u].y_tile0};
                     const int tiles = (segs[u].nf + 63) / 64;
                     for (int i = 0; i < tiles; ++i)
-                        hmap[segs[u].x_tile0 + i] = XTile{segs[u].out_row0 + 64ll * i, std::min(64, segs[u].nf - 64 * i), segs[u].y_tile0 + i};
+                        hmap[segs[u].x_tile0 + i] = XTile{segs[u].out_row0 + 64ll * i * segs[u].row_step, std::min(64, segs[u].nf - 64 * i) | (segs[u].row_step << 8), segs[u].y_tile0 + i};
                 }
                 const size_t b_list = list.size() * sizeof(int4), b_segs = (hsegs.size() * sizeof(SegDev) + 15) / 16 * 16, b_map = hmap.size() * sizeof(XTile);
                 if (tl->cap < b_list + b_segs + b_map) {

@@ -920,18 +920,41 @@ pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t 
         return PVQ_ERR_INVALID_ARG;
     }
     PVQ_HIP(hipSetDevice(device_id_));
+    // The block-DFT path takes the hop itself (r = 1), or — a hop it cannot take but whose r-fold it can, 800 -> 1 600 — r interleaved
+    // block grids of hop r * hop: grid i holds the frames i, i + r, ... (each hop' block is then transformed once per grid)
+    const size_t r = blockdft_hop_factor(hop);
     bool use_block = false;
     if (algo_ == PVQ_ALGO_BLOCKDFT) {
-        if (!blockdft_applicable(hop)) {
-            set_last_error("block-DFT path needs a power-of-two hop that divides every analysis window");
+        if (r == 0) {
+            set_last_error("block-DFT path: no multiple r * hop (r = 1, 2, 4, 8, 16) is a multiple of 64 samples that the windows hold at most 16 times "
+                           "(or a power of two dividing every window)");
             return PVQ_ERR_UNSUPPORTED;
         }
         use_block = true;
     } else if (algo_ == PVQ_ALGO_AUTO) {
-        use_block = blockdft_applicable(hop) && n_frames >= 64;
+        use_block = r != 0 && n_frames >= 64 * r;
     }
-    if (use_block) return launch_blockdft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
+    if (use_block && r > 1 && !blockdft_takes_streams(hop * r)) {
+        if (algo_ == PVQ_ALGO_BLOCKDFT) {
+            set_last_error("block-DFT path: this geometry runs the unfused stages, which take the hop only as it is");
+            return PVQ_ERR_UNSUPPORTED;
+        }
+        use_block = false;
+    }
+    if (use_block && r == 1) return launch_blockdft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
+    if (use_block) {
+        std::vector<StreamIn> st;
+        for (size_t i = 0; i < r && i < n_frames; ++i)
+            st.push_back(StreamIn{d_pcm, n_lead + (i + 1) * hop, n_lead + n_frames * hop, (n_frames - i + r - 1) / r, i, r});
+        return launch_blockdft_streams(st.data(), st.size(), hop * r, d_out_db, d_out_cplx, n_frames, pk, stream);
+    }
     return launch_fft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
+}
+
+size_t Vqt::blockdft_hop_factor(size_t hop) const {
+    for (size_t r = 1; r <= 16; r *= 2)
+        if (blockdft_applicable(hop * r)) return r;
+    return 0;
 }
 
 pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_lead, const size_t* n_frames, uint32_t n_streams, size_t hop,
@@ -980,22 +1003,27 @@ pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_
     // rows a stream does not fill are zero frames: nothing reads uninitialised memory, their peak outputs say "no peaks"
     if (ragged) PVQ_HIP(hipMemsetAsync(d_out_db, 0, rows_total * nb * sizeof(float), stream));
     if (total == 0) return PVQ_OK;
+    const size_t r = blockdft_hop_factor(hop);   // 1: the hop itself; > 1: r interleaved block grids of hop r * hop (Vqt::run_batch)
     bool use_block = false;
     if (algo_ == PVQ_ALGO_BLOCKDFT) {
-        if (!blockdft_applicable(hop)) {
-            set_last_error("block-DFT path needs a power-of-two hop that divides every analysis window");
+        if (r == 0 || (r > 1 && !blockdft_takes_streams(hop * r))) {
+            set_last_error("block-DFT path: no multiple r * hop (r = 1, 2, 4, 8, 16) is a multiple of 64 samples that the windows hold at most 16 times "
+                           "(or a power of two dividing every window)");
             return PVQ_ERR_UNSUPPORTED;
         }
         use_block = true;
     } else if (algo_ == PVQ_ALGO_AUTO) {
-        use_block = blockdft_applicable(hop) && total >= 64;
+        use_block = r != 0 && total >= 64 * r && (r == 1 || blockdft_takes_streams(hop * r));
     }
-    if (use_block && blockdft_takes_streams(hop)) {
+    if (use_block && blockdft_takes_streams(hop * r)) {
         std::vector<StreamIn> st;
-        st.reserve(n_streams);
-        for (uint32_t s = 0; s < n_streams; ++s)
-            if (n_frames[s] > 0) st.push_back(StreamIn{d_pcm[s], n_lead ? n_lead[s] : 0, n_frames[s], (size_t)s * stride});
-        return launch_blockdft_streams(st.data(), st.size(), hop, d_out_db, nullptr, rows_total, want_peaks ? &pk : nullptr, stream);
+        st.reserve((size_t)n_streams * r);
+        for (uint32_t s = 0; s < n_streams; ++s) {
+            const size_t lead = n_lead ? n_lead[s] : 0;
+            for (size_t i = 0; i < r && i < n_frames[s]; ++i)
+                st.push_back(StreamIn{d_pcm[s], lead + (i + 1) * hop, lead + n_frames[s] * hop, (n_frames[s] - i + r - 1) / r, (size_t)s * stride + i, r});
+        }
+        return launch_blockdft_streams(st.data(), st.size(), hop * r, d_out_db, nullptr, rows_total, want_peaks ? &pk : nullptr, stream);
     }
     // one stream per call (the FFT path: any hop; the unfused block-DFT stages), the peaks once over all rows
     for (uint32_t s = 0; s < n_streams; ++s) {

@@ -124,7 +124,12 @@ class Vqt {
                                float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
     bool blockdft_applicable(size_t hop) const;
     bool blockdft_takes_streams(size_t hop);
-    struct StreamIn { const float* d_pcm; size_t n_lead, n_frames, out_row0; };   // one stream of a many-streams call: its frames go to output rows out_row0 ...
+    // One run of frames for the block-DFT path: frame f' (of n_frames) ends at sample first_end + f' * hop of a buffer of n_samples
+    // valid samples (zeros before it and after it) and goes to output row out_row0 + f' * row_step.  A stream of a many-streams call is
+    // one run (first_end = n_lead + hop, row_step 1); a hop the path cannot take itself but whose r-fold it can (800 -> 1 600) is r
+    // interleaved runs of hop r * hop, run i holding the frames i, i + r, ... (first_end = n_lead + (i + 1) hop, row_step r).
+    struct StreamIn { const float* d_pcm; size_t first_end, n_samples, n_frames, out_row0, row_step; };
+    size_t blockdft_hop_factor(size_t hop) const;   // smallest r in {1, 2, 4, 8, 16} with blockdft_applicable(r * hop), 0 if none
     pvq_status launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t hop, float* d_out_db, float* d_out_cplx, size_t rows_total,
                                        const PeakParamsDev* pk, hipStream_t stream);
     pvq_status prepare_blockdft(size_t hop);

@@ -24,7 +24,7 @@ def rate(v, algo, hop, nf, d_pcm, bufs, reps):
 
 def main():
     lines = []
-    for name, sr, octaves, bpo, hops in (("48 kHz / 252 bins", 48000.0, 7, 36, (1600, 3200, 1280, 256)), ("22 050 Hz / 588 bins (reference default)", 22050.0, 7, 84, (1600, 704, 256)),
+    for name, sr, octaves, bpo, hops in (("48 kHz / 252 bins", 48000.0, 7, 36, (1600, 800, 3200, 1280, 256)), ("22 050 Hz / 588 bins (reference default)", 22050.0, 7, 84, (1600, 704, 256)),
                                          ("96 kHz / 360 bins", 96000.0, 10, 36, (3200,))):
         pp = P.VqtParameters(sr=sr, range=P.VqtRange(55.0 if sr < 90000 else 27.5, octaves, bpo))
         v = P.Vqt.new(pp, 0)

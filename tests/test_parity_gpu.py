@@ -151,33 +151,38 @@ def test_blockdft_other_hops_vs_oracle(hop, nf):
     assert_parity(db, cx, wdb, wcx)
 
 
-@pytest.mark.parametrize("name,hop,nf", [("bench_48k_252", 1600, 700), ("bench_48k_252", 320, 900), ("bench_48k_252", 1280, 520), ("bench_48k_252", 3200, 300),
-                                         ("bench_48k_288", 1600, 300), ("default_22k_588", 1600, 400), ("default_22k_588", 2240, 300),
-                                         ("hires_96k_360", 3200, 300), ("serial_22k_180", 704, 400)])
+@pytest.mark.parametrize("name,hop,nf", [("bench_48k_252", 1600, 700), ("bench_48k_252", 800, 900), ("bench_48k_252", 320, 1300), ("bench_48k_252", 1280, 520),
+                                         ("bench_48k_252", 3200, 300), ("bench_48k_252", 400, 1100), ("bench_48k_288", 1600, 300), ("default_22k_588", 1600, 400),
+                                         ("default_22k_588", 2240, 300), ("default_22k_588", 32, 2100), ("hires_96k_360", 3200, 300), ("serial_22k_180", 704, 400)])
 def test_blockdft_general_hops_vs_oracle(name, hop, nf):
-    """Hops that are a multiple of 64 but do NOT divide the windows — 1 600 samples = 30 analyses per second at 48 kHz, the cadence of
-    pitchvis_serial/src/main.rs:41, 3 200 = 15 per second, 320 / 704 / 1 280 / 2 240 odd multiples — on the block-DFT path's general
-    form (blockdft_gemm_gen: whole hop blocks + the window's remainder, Horner combine; windows shorter than the hop are the
-    remainder GEMM alone), against the oracle's per-frame FFT route on the same PCM, with the same parity bars as every other path,
-    from a stream start (zeros before it: range-checked tiles) and with a lead that is no multiple of anything."""
+    """Hops the power-of-two block-DFT form cannot take, on the block-DFT path all the same:
+      * a multiple of 64 that does not divide the windows — 1 600 samples = 30 analyses per second at 48 kHz, the cadence of
+        pitchvis_serial/src/main.rs:41; 3 200, 1 280, 2 240, 704 — runs blockdft_gemm_gen (whole hop blocks + the window's remainder,
+        Horner combine; windows shorter than the hop are the remainder GEMM alone);
+      * a hop whose r-fold (r = 2, 4, ...) is such a multiple, or a power of two — 800 = the viewer's 60 analyses per second at 48 kHz
+        (pitchvis_viewer/src/app/desktop_app.rs:18) -> 2 x 1 600, 320 -> 4 x 1 280, 400 -> 4 x 1 600, 32 -> 2 x 64 — runs r interleaved
+        block grids of hop r * hop (grid i holds the frames i, i + r, ...),
+    against the oracle's per-frame FFT route on the same PCM, with the same parity bars as every other path, from a stream start
+    (zeros before it: range-checked tiles) and with a lead that is no multiple of anything."""
     pp, op = get_geom(name)
     v = P.Vqt.new(pp, 0)
     ov = O.OracleVqt(op)
     for n_lead in (0, 4321):
         algo_id = _set_algo(v, P.ALGO_BLOCKDFT)
-        try:
-            pcm = white_noise(n_lead + hop * nf, 0xB10C + hop)
-            db, cx = run_gpu(v, pcm, hop, nf, n_lead)
-        except P.PvqError as e:   # more than 16 whole hop blocks in the longest window: this hop stays on the FFT path
-            assert e.status == 7 and hop * 16 < max(g.window_size() for g in v.kernel().window_groups)
-            pytest.skip("general block-DFT form not applicable to this hop")
+        pcm = white_noise(n_lead + hop * nf, 0xB10C + hop)
+        db, cx = run_gpu(v, pcm, hop, nf, n_lead)
         assert v.last_algo() == algo_id
         wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
         assert_parity(db, cx, wdb, wcx, xpeak=input_peak(pcm, hop, nf, n_lead, v.window_union), sr=op.sr)
-    # ALGO_AUTO takes the same path for such a hop, and the FFT path agrees with it to the parity bars
+    # ALGO_AUTO takes the same path for such a hop
     _set_algo(v, P.ALGO_AUTO)
     db2, cx2 = run_gpu(v, pcm, hop, nf, n_lead)
     assert v.last_algo() == P.ALGO_BLOCKDFT and np.array_equal(db2, db)
+    # a hop with no such multiple (735 = pitchvis_serial's 1 / 30 s at 22 050 Hz: odd) stays on the FFT path, and says so when forced
+    _set_algo(v, P.ALGO_BLOCKDFT)
+    with pytest.raises(P.PvqError) as e:
+        run_gpu(v, pcm[:735 * 64], 735, 64, 0)
+    assert e.value.status == 7
 
 
 @pytest.mark.parametrize("algo", ALGOS)

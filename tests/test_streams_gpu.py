@@ -68,7 +68,7 @@ def _check_equal(v, pcms, hop, frames, leads, stride, max_peaks=48):
 
 @pytest.mark.parametrize("name,hop", [("bench_48k_252", 256), ("bench_48k_288", 256), ("default_22k_588", 256), ("hires_96k_360", 128),
                                       ("hires_96k_840", 128), ("serial_22k_180", 256), ("bench_48k_252", 64), ("bench_48k_252", 1024),
-                                      ("bench_48k_252", 1600), ("default_22k_588", 1344)])   # (the last two: general hops, blockdft_gemm_gen)
+                                      ("bench_48k_252", 1600), ("default_22k_588", 1344), ("bench_48k_252", 800)])   # (general hops, blockdft_gemm_gen; 800: two interleaved grids of 1 600)
 def test_streams_equal_single_stream_calls_bit_for_bit(name, hop):
     pp, _ = get_geom(name)
     v = P.Vqt.new(pp, 0)
@@ -109,10 +109,11 @@ def test_streams_sub_batching_and_long_streams():
 
 
 def test_streams_general_hop_falls_back_per_stream():
-    """hop 800 (the viewer's 60 fps cadence at 48 kHz): no block-DFT; the FFT path runs stream by stream behind the same entry point"""
+    """hop 735 (pitchvis_serial's 1 / 30 s at 22 050 Hz: odd, no multiple of it suits the block-DFT path): the FFT path runs stream by
+    stream behind the same entry point"""
     pp, _ = get_geom("bench_48k_252")
     v = P.Vqt.new(pp, 0)
-    hop = 800
+    hop = 735
     frames, leads = [90, 33, 0, 120], [0, 7000, 0, 100]
     pcms = _streams(len(frames), hop, frames, leads, 4000)
     _check_equal(v, pcms, hop, frames, leads, stride=128)
