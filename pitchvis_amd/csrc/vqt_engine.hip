@@ -709,6 +709,9 @@ Vqt::~Vqt() {
         if (ws_out_) (void)hipFree(ws_out_);
         if (ws_misc_) (void)hipFree(ws_misc_);
         if (ws_flags_) (void)hipFree(ws_flags_);
+        for (void* b : multi_buf_)
+            if (b) (void)hipFree(b);
+        if (multi_stream_) (void)hipStreamDestroy(multi_stream_);
         if (host_streams_ready_)
             for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(host_streams_[i]);
         for (hipEvent_t e : host_events_) (void)hipEventDestroy(e);
@@ -1247,13 +1250,28 @@ pvq_status Vqt::analyze_batch(const float* db, size_t n_frames, const AnalysisPa
 // several handles, one host stream (multi-device driver)
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct DevBuf {   // scoped device allocation
+struct MultiBuf {   // (a view of one of the handle's shard buffers)
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     template <typename T> T* as() { return static_cast<T*>(p); }
 };
 }  // namespace
+
+// A handle's shard resources for the multi-device driver: one stream and six grow-only device buffers, kept between calls (a call per
+// shard used to pay a hipStreamCreate and up to six hipMalloc / hipFree: milliseconds, and every hipFree synchronises the device).
+pvq_status Vqt::multi_buffers(const size_t (&bytes)[6], void* (&out)[6], hipStream_t* st) {
+    if (!multi_stream_) PVQ_HIP(hipStreamCreateWithFlags(&multi_stream_, hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i) {
+        if (bytes[i] == 0) {
+            out[i] = nullptr;
+            continue;
+        }
+        pvq_status e = ensure_workspace(&multi_buf_[i], &multi_cap_[i], bytes[i]);
+        if (e != PVQ_OK) return e;
+        out[i] = multi_buf_[i];
+    }
+    *st = multi_stream_;
+    return PVQ_OK;
+}
 
 pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const float* pcm, size_t n_lead, size_t hop, size_t n_frames,
                                const AnalysisParameters& ap, float* out_db, uint32_t* peak_mask, uint32_t* peak_count, float* center,
@@ -1314,14 +1332,18 @@ pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const fl
             const size_t lead = hop_begin - begin, n_samp = lead + (size_t)sh.n_frames * hop, nf = (size_t)sh.n_frames;
             Vqt* v = handles[g];
             if (hipSetDevice(v->device()) != hipSuccess) return fail(PVQ_ERR_DEVICE, "hipSetDevice failed");
+            // the handle's own stream and grow-only shard buffers (kept between calls); with page-locked caller arrays (pvq_host_alloc)
+            // the copies below are asynchronous DMA, with pageable ones the runtime stages them
+            MultiBuf d_pcm, d_db, d_mask, d_count, d_center, d_size;
             hipStream_t st = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(PVQ_ERR_DEVICE, "hipStreamCreate failed");
-            struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
-            DevBuf d_pcm, d_db, d_mask, d_count, d_center, d_size;
-            bool ok = d_pcm.alloc(n_samp * 4) == hipSuccess && d_db.alloc(nf * nb * 4) == hipSuccess;
-            if (ok && want_peaks) ok = d_mask.alloc(nf * words * 4) == hipSuccess && d_count.alloc(nf * 4) == hipSuccess;
-            if (ok && center) ok = d_center.alloc(nf * max_peaks * 4) == hipSuccess && d_size.alloc(nf * max_peaks * 4) == hipSuccess;
-            if (!ok) return fail(PVQ_ERR_DEVICE, "hipMalloc failed for a shard's buffers");
+            {
+                const size_t bytes[6] = {n_samp * 4, nf * nb * 4, want_peaks ? nf * words * 4 : 0, want_peaks ? nf * 4 : 0,
+                                         center ? nf * max_peaks * 4 : 0, center ? nf * max_peaks * 4 : 0};
+                void* ptrs[6];
+                const pvq_status bs = v->multi_buffers(bytes, ptrs, &st);
+                if (bs != PVQ_OK) return fail(bs, get_last_error());
+                d_pcm.p = ptrs[0]; d_db.p = ptrs[1]; d_mask.p = ptrs[2]; d_count.p = ptrs[3]; d_center.p = ptrs[4]; d_size.p = ptrs[5];
+            }
             if (hipMemcpyAsync(d_pcm.p, pcm + begin, n_samp * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(PVQ_ERR_DEVICE, "upload failed");
             if (center) {   // entries beyond a frame's count are left as the caller passed them: start from the caller's contents
                 const size_t off = (size_t)sh.first_frame * max_peaks;

@@ -163,6 +163,13 @@ class Vqt {
     void* ws_out_ = nullptr;  size_t ws_out_cap_ = 0;
     void* ws_misc_ = nullptr; size_t ws_misc_cap_ = 0;
     void* ws_flags_ = nullptr; size_t ws_flags_cap_ = 0;  // per-frame redo flags of the peak kernels
+    // the multi-device driver's per-handle shard buffers (PCM, dB, mask, count, center, size) and stream, grow-only
+    void* multi_buf_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t multi_cap_[6] = {0, 0, 0, 0, 0, 0};
+    hipStream_t multi_stream_ = nullptr;
+   public:
+    pvq_status multi_buffers(const size_t (&bytes)[6], void* (&out)[6], hipStream_t* st);   // (used by analyze_batch_multi's workers)
+   private:
 };
 
 // One stream of host PCM analysed on several handles at once (one host thread per handle; handles may sit on different devices

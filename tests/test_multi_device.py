@@ -82,3 +82,37 @@ def test_k_virtual_shards_equal_one_handle_bit_for_bit(geom, hop):
     other = P.Vqt.new(P.VqtParameters(sr=48000.0, range=P.VqtRange(55.0, 6, 36)), 0)
     with pytest.raises(P.PvqError):
         P.Vqt.analyze_batch_multi([handles[0], other], pcm, hop, n_frames, n_lead=n_lead)
+
+
+@pytest.mark.gpu
+def test_fewer_frames_than_handles_and_repeated_calls():
+    """5 frames over 8 handles: three shards are empty and simply do nothing; and the handles' persistent shard buffers (one stream and
+    six grow-only device buffers per handle) are reused by a second, larger, then a smaller call with the same bits as one handle."""
+    pp, _ = get_geom("bench_48k_252")
+    hop = 256
+    handles = [P.Vqt.new(pp, 0) for _ in range(8)]
+    for n_frames in (5, 700, 64, 5):
+        pcm = white_noise(hop * n_frames, 31 + n_frames)
+        ref = P.Vqt.analyze_batch_multi(handles[:1], pcm, hop, n_frames, max_peaks=32)
+        got = P.Vqt.analyze_batch_multi(handles, pcm, hop, n_frames, max_peaks=32)
+        for name, a, b in zip(("db", "mask", "count", "center", "size"), ref, got):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n_frames, name)
+
+
+@pytest.mark.gpu
+def test_a_non_finite_sample_in_exactly_one_shard_names_it():
+    """NaN / Inf policy through the multi-device driver: the shard whose frames see the bad sample returns PVQ_ERR_NONFINITE_INPUT and the
+    error text names it; a clean call on the same handles afterwards succeeds (every worker reads and clears its own handle's flag)."""
+    pp, _ = get_geom("bench_48k_252")
+    hop, n_frames, k = 256, 4000, 4
+    handles = [P.Vqt.new(pp, 0) for _ in range(k)]
+    pcm = white_noise(hop * n_frames, 5)
+    clean = P.Vqt.analyze_batch_multi(handles, pcm, hop, n_frames, max_peaks=16)
+    bad = pcm.copy()
+    bad[2600 * hop + 17] = np.inf   # frames 2600 .. 2663 see it: shard 2 of 4 (frames 2000 .. 2999) only
+    with pytest.raises(P.PvqError) as e:
+        P.Vqt.analyze_batch_multi(handles, bad, hop, n_frames, max_peaks=16)
+    assert e.value.status == _lib.PVQ_ERR_NONFINITE_INPUT and "shard 2" in str(e.value)
+    again = P.Vqt.analyze_batch_multi(handles, pcm, hop, n_frames, max_peaks=16)
+    for a, b in zip(clean, again):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
