@@ -954,6 +954,16 @@ pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t 
     return launch_fft_path(d_pcm, n_lead, hop, n_frames, d_out_db, d_out_cplx, pk, stream);
 }
 
+// which path run_batch takes for a batch of this shape (the multi-device driver decides once for the WHOLE stream, so that a shard of a
+// few frames runs the path the unsharded stream runs: the two paths agree to the parity bars, not bit for bit)
+pvq_algo Vqt::resolve_algo(size_t hop, size_t n_frames) {
+    if (algo_ == PVQ_ALGO_FFT) return PVQ_ALGO_FFT;
+    const size_t r = blockdft_hop_factor(hop);
+    if (r == 0 || (r > 1 && !blockdft_takes_streams(hop * r))) return algo_ == PVQ_ALGO_BLOCKDFT ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;   // (forced: run_batch reports the error)
+    if (algo_ == PVQ_ALGO_BLOCKDFT) return PVQ_ALGO_BLOCKDFT;
+    return n_frames >= 64 * r ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;
+}
+
 size_t Vqt::blockdft_hop_factor(size_t hop) const {
     for (size_t r = 1; r <= 16; r *= 2)
         if (blockdft_applicable(hop * r)) return r;
@@ -1312,6 +1322,12 @@ pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const fl
     const size_t nb = handles[0]->n_bins(), words = (nb + 31) / 32;
     const size_t wu = handles[0]->plan().window_union;
     const bool want_peaks = peak_mask || peak_count || center;
+    // one decision for the whole stream (what ONE handle would do with it), applied to every shard
+    if (hipSetDevice(handles[0]->device()) != hipSuccess) {
+        set_last_error("hipSetDevice failed");
+        return PVQ_ERR_DEVICE;
+    }
+    const pvq_algo whole = handles[0]->resolve_algo(hop, n_frames);
     std::vector<pvq_status> status(n_handles, PVQ_OK);
     std::vector<std::string> message(n_handles);
     auto work = [&](uint32_t g) {
@@ -1352,11 +1368,14 @@ pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const fl
                     return fail(PVQ_ERR_DEVICE, "upload failed");
             }
             pvq_status rs;
+            const pvq_algo own = v->algo();
+            v->set_algo(whole);
             if (want_peaks)
                 rs = v->vqt_analyze_batch_device(d_pcm.as<float>(), lead, hop, nf, ap, d_db.as<float>(), d_mask.as<uint32_t>(), d_count.as<uint32_t>(),
                                                  center ? d_center.as<float>() : nullptr, center ? d_size.as<float>() : nullptr, max_peaks, st);
             else
                 rs = v->calculate_batch_db_device(d_pcm.as<float>(), lead, hop, nf, d_db.as<float>(), nullptr, st);
+            v->set_algo(own);
             if (rs != PVQ_OK) return fail(rs, get_last_error());
             const size_t f0 = (size_t)sh.first_frame;
             bool cp = hipMemcpyAsync(out_db + f0 * nb, d_db.p, nf * nb * 4, hipMemcpyDeviceToHost, st) == hipSuccess;

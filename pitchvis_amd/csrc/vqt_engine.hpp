@@ -84,6 +84,8 @@ class Vqt {
                              uint32_t* peak_count, float* center, float* size, uint32_t max_peaks);
 
     void set_algo(pvq_algo a) { algo_ = a; }
+    pvq_algo algo() const { return algo_; }
+    pvq_algo resolve_algo(size_t hop, size_t n_frames);   // the path a batch of this shape takes under the current setting
     // block-DFT GEMM arithmetic: exact fp32 MFMA, or the split-bf16 (3 x bf16, fp32 accumulate) form
     void set_gemm_split_bf16(bool on) { gemm_split_bf16_ = on; }
     void set_workspace_limit(size_t bytes) { workspace_limit_ = bytes ? bytes : ((size_t)1 << 30); }   // block-DFT spectrum workspace

@@ -209,6 +209,54 @@ def test_gemm_precision_switch_on_one_handle():
     assert np.abs(a1 - b1)[loud].max() <= 2e-2
 
 
+def test_tile_list_cache_evicts_and_rebuilds_under_work_in_flight():
+    """ONE handle walked through nine distinct launch shapes and back, without a synchronisation between the calls: (frames, lead,
+    stream length, GEMM arithmetic, single stream / several streams, power-of-two / general hop).  The fused kernels' tile lists —
+    which tiles lie wholly inside their stream and may take 16-byte loads / pair up — are cached in four slots keyed on exactly that
+    geometry, so this sequence evicts and rebuilds lists while earlier launches are still queued.  Round 3's in-round GPU fault
+    ("The tile-list fault of round 3") was a list reused for a geometry it was not built for; here every call must give
+    the bits a FRESH handle gives for the same shape, on the first pass and on the way back."""
+    pp, _ = get_geom("bench_48k_252")
+    hop = 256
+    shapes = [  # (frames, lead, arithmetic, n_streams, hop)
+        (3000, 0, P.GEMM_F32, 1, 256), (3000, 16128, P.GEMM_F32, 1, 256), (1000, 0, P.GEMM_F32, 1, 256), (1000, 500, P.GEMM_BF16X3, 1, 256),
+        (5000, 0, P.GEMM_F32, 1, 256), (3000, 0, P.GEMM_BF16X3, 1, 256), (700, 123, P.GEMM_F32, 3, 256), (2999, 0, P.GEMM_F32, 1, 256),
+        (600, 77, P.GEMM_F32, 1, 1600),
+    ]
+    pcms = {}
+    for i, (nf, lead, _, ns, hp) in enumerate(shapes):
+        pcms[i] = [torch.from_numpy(white_noise(lead + hp * nf, 900 + 7 * i + s)).cuda() for s in range(ns)]
+
+    def call(v, i, out):
+        nf, lead, arith, ns, hp = shapes[i]
+        v.set_gemm_precision(arith)
+        if ns == 1:
+            v.calculate_batch_db_device(pcms[i][0], hp, nf, out[0], n_lead=lead)
+        else:
+            v.batch_streams_device(pcms[i], hp, [nf] * ns, out, nf, n_leads=[lead] * ns)
+
+    v = P.Vqt.new(pp, 0)
+    v.set_algo(P.ALGO_BLOCKDFT)
+    order = list(range(len(shapes))) + list(range(len(shapes) - 1, -1, -1)) + [0, 4, 1, 6, 8, 3]
+    outs = []
+    for i in order:   # no synchronisation in between: the next call's list upload meets the previous launches still in flight
+        o = torch.full((shapes[i][3], shapes[i][0], v.n_bins), -1.0, device="cuda")
+        call(v, i, o)
+        outs.append((i, o))
+    torch.cuda.synchronize()
+    v.input_status()
+    fresh = {}
+    for i in range(len(shapes)):
+        w = P.Vqt.new(pp, 0)
+        w.set_algo(P.ALGO_BLOCKDFT)
+        o = torch.full((shapes[i][3], shapes[i][0], v.n_bins), -1.0, device="cuda")
+        call(w, i, o)
+        torch.cuda.synchronize()
+        fresh[i] = o
+    for i, o in outs:
+        assert torch.equal(o, fresh[i]), (i, shapes[i], int((o != fresh[i]).sum()))
+
+
 def test_unfused_fallback_stages_in_a_subprocess():
     """The unfused GEMM + combine stages (taken when a geometry has more than 8 window groups; developer knob
     PVQ_NO_FUSE=1) against the FFT path, in a child process because the knob is read once per process."""
