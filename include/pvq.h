@@ -346,7 +346,9 @@ void pvq_analysis_batch_destroy(pvq_analysis_batch *b);
 pvq_status pvq_analysis_batch_update_vqt_smoothing_duration(pvq_analysis_batch *b, int has_duration, uint64_t duration_ns);
 /* AnalysisState::preprocess (analysis.rs:288) for n_frames frames of every stream, in order: d_db [n_streams][n_frames][n_bins]
  * (device).  frame_time_ns applies to every frame unless frame_times_ns (HOST array of n_frames) is given.  Asynchronous on
- * `stream`. */
+ * `stream` — except that a call whose frame time(s) differ from the previous call's first waits for `stream` (the table of EMA weights
+ * 1 - exp(-2 frame_time / horizon), built on the host with its libm so that the device follows the host AnalysisState bit for bit, is
+ * replaced). */
 pvq_status pvq_analysis_batch_preprocess_device(pvq_analysis_batch *b, const float *d_db, size_t n_frames, uint64_t frame_time_ns,
                                                 const uint64_t *frame_times_ns, const pvq_analysis_batch_outputs *outs,
                                                 void *stream);

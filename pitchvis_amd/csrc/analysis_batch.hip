@@ -615,18 +615,25 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
                 row[3] = 0.0f;
                 for (size_t h = 0; h < tab_n; ++h) row[4 + h] = alpha(Duration::from_millis(h));
             }
+            // the table of the last call is reused as it stands when nothing it depends on changed (the usual case: one frame time for
+            // every call) — no upload, no wait; otherwise the stream is drained first: an earlier call may still read the buffer
             const size_t need = tab.size() * sizeof(float) + rows.size() * sizeof(uint32_t);
-            if (tab_cap_ < need) {
-                if (d_tab_) PVQ_HIP(hipFree(d_tab_));
-                d_tab_ = nullptr;
-                tab_cap_ = 0;
+            const bool same = rows.empty() && d_tab_ && tab == tab_host_;
+            if (!same) {
                 PVQ_HIP(hipStreamSynchronize(stream));
-                PVQ_HIP(hipMalloc(&d_tab_, need));
-                tab_cap_ = need;
+                if (tab_cap_ < need) {
+                    PVQ_HIP(hipDeviceSynchronize());   // (a call on another stream may read it too)
+                    if (d_tab_) PVQ_HIP(hipFree(d_tab_));
+                    d_tab_ = nullptr;
+                    tab_cap_ = 0;
+                    tab_host_.clear();
+                    PVQ_HIP(hipMalloc(&d_tab_, need));
+                    tab_cap_ = need;
+                }
+                // (synchronous copies from pageable host memory)
+                PVQ_HIP(hipMemcpy(d_tab_, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+                tab_host_ = rows.empty() ? tab : std::vector<float>();
             }
-            // (synchronous copies from pageable host memory: the vectors may go out of scope when this returns)
-            PVQ_HIP(hipStreamSynchronize(stream));   // an earlier call on this stream may still read the table
-            PVQ_HIP(hipMemcpy(d_tab_, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
             a.alpha_tab = static_cast<const float*>(d_tab_);
             a.tab_n = (int)tab_n;
             a.tab_stride = (int)stride;

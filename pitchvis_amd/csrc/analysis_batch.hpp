@@ -13,6 +13,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <vector>
 
 #include "../../include/pvq.h"
 #include "analysis_host.hpp"
@@ -71,6 +72,7 @@ class AnalysisBatch {
     size_t times_cap_ = 0;
     void* d_tab_ = nullptr;            // EMA weights of the running call (host libm), then the frames' row indices
     size_t tab_cap_ = 0;
+    std::vector<float> tab_host_;      // what d_tab_ holds (constant frame time: reused by the next call without an upload)
 };
 
 }  // namespace pvq

@@ -2448,7 +2448,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             while (left > 0) {
                 const size_t nf = std::min(left, chunk);
                 const size_t tiles = (nf + 63) / 64;
-                if (launches.empty() || used + tiles > budget) {
+                if (launches.empty() || used + tiles > budget || launches.back().size() >= 0xFFFFu) {   // (a tile-list entry names its run in 16 bits)
                     launches.emplace_back();
                     used = 0;
                 }
