@@ -679,8 +679,13 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
 #define PVQ_AB_LAUNCH(NK) (dist ? launch(analysis_batch_preprocess<NK, true, 2>) : launch(analysis_batch_preprocess<NK, false, 2>))
     (void)occ;
 #endif
+    // bins per lane: the smallest instantiation that holds the frame (588 bins — the reference's default 7 x 84 — on 16 bins per lane
+    // ran at one wave per SIMD: 256 registers; on 10 it keeps two)
     if (a.n_bins <= 256) lst = PVQ_AB_LAUNCH(4);
+    else if (a.n_bins <= 384) lst = PVQ_AB_LAUNCH(6);
     else if (a.n_bins <= 512) lst = PVQ_AB_LAUNCH(8);
+    else if (a.n_bins <= 640) lst = PVQ_AB_LAUNCH(10);
+    else if (a.n_bins <= 768) lst = PVQ_AB_LAUNCH(12);
     else lst = PVQ_AB_LAUNCH(16);
 #undef PVQ_AB_LAUNCH
     if (lst != PVQ_OK) return lst;

@@ -170,7 +170,8 @@ def _compare_stream(tally, g, s, w, n_frames, max_peaks, tol, where):
 
 
 @pytest.mark.parametrize("bpo,octaves,n_streams,n_frames,mode", [(36, 7, 256, 1000, "default"), (84, 7, 8, 300, "default"),
-                                                                  (36, 5, 16, 300, "none"), (36, 7, 16, 300, "retuned")])
+                                                                  (36, 5, 16, 300, "none"), (36, 7, 16, 300, "retuned"),
+                                                                  (36, 10, 6, 260, "default"), (84, 9, 5, 240, "default"), (84, 12, 4, 220, "default")])   # (360 / 756 / 1 008 bins: 6 / 12 / 16 bins per lane)
 def test_gpu_streams_follow_the_oracle(bpo, octaves, n_streams, n_frames, mode):
     rng_ = P.VqtRange(55.0, octaves, bpo)
     nb = octaves * bpo
