@@ -120,9 +120,11 @@ struct BlockDftTables {
         long long pcm_off, base, out_row0;
         unsigned pcm_bytes;
         int nf, x_tile0, y_tile0, row_step;
+        unsigned long long slot_hash;   // a run over a staged buffer of many streams: hash of its slots (0: none), its grid offset and first frame
+        long long grid_i, fbeg;
         bool operator==(const SegKey& o) const {
             return pcm_off == o.pcm_off && base == o.base && out_row0 == o.out_row0 && pcm_bytes == o.pcm_bytes && nf == o.nf && x_tile0 == o.x_tile0 && y_tile0 == o.y_tile0 &&
-                   row_step == o.row_step;
+                   row_step == o.row_step && slot_hash == o.slot_hash && grid_i == o.grid_i && fbeg == o.fbeg;
         }
     };
     struct TileList {
@@ -2539,7 +2541,10 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             k.y_tile0 = (int)yt_n;
             k.out_row0 = (long long)(S.out_row0 + r.fbeg * S.row_step);
             k.row_step = (int)S.row_step;
-            strided |= S.row_step != 1;
+            k.slot_hash = S.slots ? (S.slot_hash | 1ull) : 0ull;
+            k.grid_i = (long long)S.grid_i;
+            k.fbeg = (long long)r.fbeg;
+            strided |= S.row_step != 1 || S.slots != nullptr;
             xt_n += (r.nf + 63) / 64;
             yt_n += (r.nf + (size_t)std::max(t->nb_max - 64, 0) + 63) / 64;
             nf_launch += r.nf;
@@ -2600,7 +2605,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             // (a launch of one run hands its stream pointer and output rows over in the kernel arguments: they are not part of its key,
             // so the middle sub-batches of a long stream share one list, and so do different buffers of one geometry)
             std::vector<BlockDftTables::SegKey> key = segs;
-            if (!multi) key[0].pcm_off = key[0].out_row0 = 0;
+            if (!multi) key[0].pcm_off = key[0].out_row0 = key[0].fbeg = 0;
             // kind 0: the tiles of a power-of-two hop (GEMM + tree); 1 / 2: the remainder / whole-block tiles of a general hop
             auto get_list = [&](int kind, BlockDftTables::TileList*& tl) -> pvq_status {
             tl = nullptr;
@@ -2735,8 +2740,25 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 for (size_t u = 0; u < segs.size(); ++u) {
                     hsegs[u] = SegDev{segs[u].pcm_off, segs[u].base, segs[u].pcm_bytes, segs[u].nf, segs[u].x_tile0, segs[u].y_tile0};
                     const int tiles = (segs[u].nf + 63) / 64;
-                    for (int i = 0; i < tiles; ++i)
-                        hmap[segs[u].x_tile0 + i] = XTile{segs[u].out_row0 + 64ll * i * segs[u].row_step, std::min(64, segs[u].nf - 64 * i) | (segs[u].row_step << 8), segs[u].y_tile0 + i};
+                    const StreamIn& S = st[L[u].stream];
+                    for (int i = 0; i < tiles; ++i) {
+                        XTile xt{segs[u].out_row0 + 64ll * i * segs[u].row_step, std::min(64, segs[u].nf - 64 * i) | (segs[u].row_step << 8), segs[u].y_tile0 + i};
+                        if (S.slots) {   // frame t of the run = frame grid_i + row_step * t of the staged buffer: the slot it falls into names its rows
+                            const size_t rs = S.row_step, t0 = L[u].fbeg + 64 * (size_t)i, v0 = S.grid_i + rs * t0;
+                            const Slot* lo = S.slots;   // the last slot that starts at or before v0 (slots ascend; they start on multiples of 64 row_step frames)
+                            size_t n = S.n_slots;
+                            while (n > 1) {
+                                const size_t h = n / 2;
+                                if (lo[h].vframe0 <= v0) { lo += h; n -= h; } else n = h;
+                            }
+                            long long live = 0;
+                            if (S.n_slots && lo->vframe0 <= v0 && v0 < lo->vframe0 + lo->n_frames)
+                                live = std::min<long long>((long long)((lo->vframe0 + lo->n_frames - v0 + rs - 1) / rs), std::min(64, segs[u].nf - 64 * i));
+                            xt.out_row0 = S.n_slots ? (long long)(lo->out_row0 + (v0 - std::min(v0, lo->vframe0))) : 0;
+                            xt.live_step = (int)live | ((int)rs << 8);
+                        }
+                        hmap[segs[u].x_tile0 + i] = xt;
+                    }
                 }
                 const size_t b_list = list.size() * sizeof(int4), b_segs = (hsegs.size() * sizeof(SegDev) + 15) / 16 * 16, b_map = hmap.size() * sizeof(XTile);
                 if (tl->cap < b_list + b_segs + b_map) {

@@ -130,7 +130,17 @@ class Vqt {
     // valid samples (zeros before it and after it) and goes to output row out_row0 + f' * row_step.  A stream of a many-streams call is
     // one run (first_end = n_lead + hop, row_step 1); a hop the path cannot take itself but whose r-fold it can (800 -> 1 600) is r
     // interleaved runs of hop r * hop, run i holding the frames i, i + r, ... (first_end = n_lead + (i + 1) hop, row_step r).
-    struct StreamIn { const float* d_pcm; size_t first_end, n_samples, n_frames, out_row0, row_step; };
+    // A run may also read a STAGED buffer that holds many short streams one behind the other, each in a slot of whole 64 r-frame tiles
+    // followed by a gap that is the next stream's history (Vqt::batch_streams_device): then `slots` says which output rows the
+    // run's frames are — frame t of the run is frame grid_i + row_step * t of the staged buffer — and out_row0 is unused.
+    struct Slot { size_t vframe0, n_frames, out_row0; };   // frames [vframe0, vframe0 + n_frames) of the staged buffer -> rows out_row0 ...
+    struct StreamIn {
+        const float* d_pcm;
+        size_t first_end, n_samples, n_frames, out_row0, row_step;
+        const Slot* slots = nullptr;
+        size_t n_slots = 0, grid_i = 0;
+        uint64_t slot_hash = 0;
+    };
     size_t blockdft_hop_factor(size_t hop) const;   // smallest r in {1, 2, 4, 8, 16} with blockdft_applicable(r * hop), 0 if none
     pvq_status launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t hop, float* d_out_db, float* d_out_cplx, size_t rows_total,
                                        const PeakParamsDev* pk, hipStream_t stream);
@@ -165,6 +175,8 @@ class Vqt {
     void* ws_out_ = nullptr;  size_t ws_out_cap_ = 0;
     void* ws_misc_ = nullptr; size_t ws_misc_cap_ = 0;
     void* ws_flags_ = nullptr; size_t ws_flags_cap_ = 0;  // per-frame redo flags of the peak kernels
+    void* ws_stage_ = nullptr; size_t ws_stage_cap_ = 0;  // many short streams staged one behind the other (batch_streams_device)
+    void* ws_stage_tab_ = nullptr; size_t ws_stage_tab_cap_ = 0;
     // the multi-device driver's per-handle shard buffers (PCM, dB, mask, count, center, size) and stream, grow-only
     void* multi_buf_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t multi_cap_[6] = {0, 0, 0, 0, 0, 0};

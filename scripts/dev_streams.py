@@ -28,7 +28,7 @@ def main():
     v = P.Vqt.new(pp, 0)
     nb, words, mp = v.n_bins, (v.n_bins + 31) // 32, 64
     lines = []
-    for n_streams, nf in ((64, 2048), (256, 512), (1024, 128), (2, 65536), (16, 8192)):
+    for n_streams, nf in ((64, 2048), (256, 512), (1024, 128), (2, 65536), (16, 8192), (32, 4096)):
         total = n_streams * nf
         pcms = [stream_slice(0x5EED0001 + s, 0, nf * HOP, "cuda") for s in range(n_streams)]
         one = stream_slice(0x5EED0001, 0, total * HOP, "cuda")
