@@ -317,7 +317,16 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
 // ------------------------------------------------------------------------------------------------
 // K1-K3 fused: FFT path, one workgroup per frame
 // ------------------------------------------------------------------------------------------------
+// many streams in one launch of the FFT path: frames are numbered through all streams; stream i holds the frames from frame0
+struct FftStream {
+    const float* pcm;
+    long long n_lead, n_samples;
+    long long row0;     // output row of its frame 0
+    long long frame0;   // global index of its frame 0 (ascending over the table)
+};
 struct FftArgs {
+    const FftStream* streams;   // nullptr: one stream, described by the fields below
+    int n_streams;
     const float* pcm;
     long long n_lead;
     long long hop;
@@ -359,9 +368,25 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
 
     for (int fg = blockIdx.x; fg * F < a.n_frames; fg += gridDim.x) {
         const bool live = fg * F + fl < a.n_frames;
-        const int frame = live ? fg * F + fl : a.n_frames - 1;   // a padding frame repeats the last one and stores nothing
+        const int gframe = live ? fg * F + fl : a.n_frames - 1;   // a padding frame repeats the last one and stores nothing
+        // the frame's stream (wave-uniform: T >= 64 threads share a frame)
+        const float* pcm = a.pcm;
+        long long n_lead = a.n_lead, n_samples = a.n_samples, frame = gframe, out_row = gframe;
+        if (a.streams) {
+            int lo = 0, n = a.n_streams;   // the last stream whose first frame is at or before gframe
+            while (n > 1) {
+                const int h = n >> 1;
+                if (a.streams[lo + h].frame0 <= gframe) { lo += h; n -= h; } else n = h;
+            }
+            const FftStream st = a.streams[lo];
+            pcm = st.pcm;
+            n_lead = st.n_lead;
+            n_samples = st.n_samples;
+            frame = gframe - st.frame0;
+            out_row = st.row0 + frame;
+        }
         // x[j] of the reference's n_fft buffer is pcm[buf0 + j]; zeros before the stream start
-        const long long buf0 = a.n_lead + (long long)(frame + 1) * a.hop - a.n_fft;
+        const long long buf0 = n_lead + (frame + 1) * a.hop - a.n_fft;
 
         for (int g = 0; g < a.n_groups; ++g) {
             const GroupDev G = a.groups[g];
@@ -376,7 +401,7 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
                     for (int u = 0; u < 8; ++u) {
                         const int i = i0 + u * T;
                         const long long sx = s0 + i;
-                        v[u] = (i < 2 * N && sx >= 0 && sx < a.n_samples) ? a.pcm[sx] : 0.0f;
+                        v[u] = (i < 2 * N && sx >= 0 && sx < n_samples) ? pcm[sx] : 0.0f;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -451,9 +476,9 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
             __syncthreads();   // the next group's gather overwrites the spectrum columns
         }
         if (a.out_cplx && live) {
-            for (int k = tl; k < a.n_bins; k += T) a.out_cplx[(size_t)frame * a.n_bins + k] = xv[k];
+            for (int k = tl; k < a.n_bins; k += T) a.out_cplx[(size_t)out_row * a.n_bins + k] = xv[k];
         }
-        db_epilogue<T>(xv, red, a.n_bins, a.out_db + (size_t)frame * a.n_bins, nullptr, tl, a.status, live);
+        db_epilogue<T>(xv, red, a.n_bins, a.out_db + (size_t)out_row * a.n_bins, nullptr, tl, a.status, live);
         __syncthreads();
     }
 }
@@ -856,7 +881,22 @@ uint32_t Vqt::last_kernel_launches(uint32_t* out, uint32_t cap) const {
 
 pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                 float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
+    return launch_fft_streams(nullptr, 0, d_pcm, n_lead, hop, n_frames, n_frames, d_out_db, d_out_cplx, pk, stream);
+}
+
+// st != nullptr: n_st streams in ONE launch (their frames numbered through; rows_total output rows for the peak stage)
+pvq_status Vqt::launch_fft_streams(const void* st_table, size_t n_st, const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, size_t rows_total,
+                                   float* d_out_db, float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     FftArgs a;
+    a.streams = nullptr;
+    a.n_streams = 0;
+    if (st_table) {
+        pvq_status es = ensure_workspace(&ws_stage_tab_, &ws_stage_tab_cap_, n_st * sizeof(FftStream));
+        if (es != PVQ_OK) return es;
+        PVQ_HIP(hipMemcpyAsync(ws_stage_tab_, st_table, n_st * sizeof(FftStream), hipMemcpyHostToDevice, stream));   // (pageable source: staged before the call returns)
+        a.streams = static_cast<const FftStream*>(ws_stage_tab_);
+        a.n_streams = (int)n_st;
+    }
     a.pcm = d_pcm;
     a.n_lead = (long long)n_lead;
     a.hop = (long long)hop;
@@ -898,7 +938,7 @@ pvq_status Vqt::launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, s
     slot_end(SLOT_FFT_FRAMES, stream);
     if (pk) {  // peak / note detection as its own launch (one wavefront per frame)
         slot_begin(SLOT_PEAKS, stream);
-        pvq_status ps = launch_peaks_kernel(d_out_db, n_frames, *pk, stream);
+        pvq_status ps = launch_peaks_kernel(d_out_db, rows_total, *pk, stream);
         slot_end(SLOT_PEAKS, stream);
         if (ps != PVQ_OK) return ps;
     }
@@ -1149,7 +1189,18 @@ pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_
         }
         return PVQ_OK;
     }
-    // one stream per call (the FFT path: any hop; the unfused block-DFT stages), the peaks once over all rows
+    if (!use_block) {   // the FFT path (any hop): all streams in ONE launch, the peaks over all rows behind it
+        std::vector<FftStream> tab;
+        long long f0 = 0;
+        for (uint32_t s = 0; s < n_streams; ++s) {
+            if (n_frames[s] == 0) continue;
+            const size_t lead = n_lead ? n_lead[s] : 0;
+            tab.push_back(FftStream{d_pcm[s], (long long)lead, (long long)(lead + n_frames[s] * hop), (long long)((size_t)s * stride), f0});
+            f0 += (long long)n_frames[s];
+        }
+        return launch_fft_streams(tab.data(), tab.size(), nullptr, 0, hop, (size_t)f0, rows_total, d_out_db, nullptr, want_peaks ? &pk : nullptr, stream);
+    }
+    // one stream per call (the unfused block-DFT stages), the peaks once over all rows
     for (uint32_t s = 0; s < n_streams; ++s) {
         if (n_frames[s] == 0) continue;
         float* out = d_out_db + (size_t)s * stride * nb;

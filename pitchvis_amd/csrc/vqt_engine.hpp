@@ -124,6 +124,8 @@ class Vqt {
                           float* d_size, uint32_t max_peaks, PeakParamsDev& out) const;
     pvq_status launch_fft_path(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                                float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);
+    pvq_status launch_fft_streams(const void* st_table, size_t n_st, const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, size_t rows_total,
+                                  float* d_out_db, float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);   // st_table: FftStream[n_st] (vqt_engine.hip) or null
     bool blockdft_applicable(size_t hop) const;
     bool blockdft_takes_streams(size_t hop);
     // One run of frames for the block-DFT path: frame f' (of n_frames) ends at sample first_end + f' * hop of a buffer of n_samples

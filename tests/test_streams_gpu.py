@@ -108,15 +108,19 @@ def test_streams_sub_batching_and_long_streams():
     _check_equal(v, pcms, hop, frames, leads, stride=9000)
 
 
-def test_streams_general_hop_falls_back_per_stream():
-    """hop 735 (pitchvis_serial's 1 / 30 s at 22 050 Hz: odd, no multiple of it suits the block-DFT path): the FFT path runs stream by
-    stream behind the same entry point"""
-    pp, _ = get_geom("bench_48k_252")
+def test_streams_odd_hop_on_the_fft_path_in_one_launch():
+    """hop 735 (pitchvis_serial's 1 / 30 s at its own 22 050 Hz: odd, no multiple of it suits the block-DFT path): the FFT path takes all
+    streams in ONE launch too (frames numbered through the streams, a binary search per frame finds its stream); same bits as
+    stream-by-stream calls; 40 streams so that workgroups hold frames of different streams side by side"""
+    pp, _ = get_geom("serial_22k_180")
     v = P.Vqt.new(pp, 0)
     hop = 735
-    frames, leads = [90, 33, 0, 120], [0, 7000, 0, 100]
+    rng = np.random.default_rng(3)
+    frames = [int(x) for x in rng.integers(0, 140, 40)]
+    frames[5] = 0
+    leads = [int(x) for x in rng.integers(0, 9000, 40)]
     pcms = _streams(len(frames), hop, frames, leads, 4000)
-    _check_equal(v, pcms, hop, frames, leads, stride=128)
+    _check_equal(v, pcms, hop, frames, leads, stride=160)
     assert v.last_algo() == P.ALGO_FFT
 
 
