@@ -34,7 +34,7 @@ def test_status_strings_cover_every_status():
     names = [L.pvq_status_string(i).decode() for i in range(10)]
     assert len(set(names)) == 10 and "unknown" not in names
     assert "non-finite" in names[_lib.PVQ_ERR_NONFINITE_INPUT] and "internal" in names[_lib.PVQ_ERR_INTERNAL]
-    assert L.pvq_abi_version() == 3
+    assert L.pvq_abi_version() == 4
 
 
 @pytest.mark.parametrize("what,text", [("bad_alloc", "out of host memory"), ("length_error", "vector"), ("int", "unknown exception")])
