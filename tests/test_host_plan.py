@@ -24,7 +24,7 @@ def test_header_symbols_all_exported():
     assert sorted(_lib.EXPORTS) == declared
     for name in declared:
         assert hasattr(L, name), f"libpvq.so lacks {name}"
-    assert L.pvq_abi_version() == 3
+    assert L.pvq_abi_version() == 4
 
 
 def test_no_oracle_dependency_in_product():
