@@ -355,6 +355,15 @@ pvq_status pvq_analysis_batch_update_vqt_smoothing_duration(pvq_analysis_batch *
 pvq_status pvq_analysis_batch_preprocess_device(pvq_analysis_batch *b, const float *d_db, size_t n_frames, uint64_t frame_time_ns,
                                                 const uint64_t *frame_times_ns, const pvq_analysis_batch_outputs *outs,
                                                 void *stream);
+/* The consumers' loop in one call, for many streams: per stream and hop what pitchvis_viewer does per rendered frame
+ * (vqt_system.rs:40-68 -> Vqt::calculate_vqt_instant_in_db, analysis_system.rs:10-20 -> AnalysisState::preprocess) and pitchvis_serial
+ * per 1 / 30 s (main.rs:205-215).  d_pcm / n_lead as for pvq_vqt_calculate_batch_db_streams, n_frames frames of EVERY stream (the
+ * batch's n_streams of them); the dB frames [n_streams][n_frames][n_bins] go through a buffer of the batch object (grow-only device
+ * memory) — or through d_db if the caller wants them — and never leave the device.  v and b must sit on the same device and share
+ * the VqtRange.  frame_time_ns: the hop's duration (hop / sr, what a live consumer measures between two analyses).  Asynchronous. */
+pvq_status pvq_analysis_batch_preprocess_pcm(pvq_analysis_batch *b, pvq_vqt *v, const float *const *d_pcm, const size_t *n_lead,
+                                             size_t n_frames, size_t hop, uint64_t frame_time_ns, float *d_db,
+                                             const pvq_analysis_batch_outputs *outs, void *stream);
 /* the state of one stream after the last call (synchronises): a pub field as pvq_analysis_state_get_field, and the two scalars */
 pvq_status pvq_analysis_batch_get_field(pvq_analysis_batch *b, uint32_t stream_index, pvq_analysis_field f, float *out);
 pvq_status pvq_analysis_batch_get_scalars(pvq_analysis_batch *b, uint32_t stream_index, float *scene_calmness,

@@ -522,6 +522,22 @@ class AnalysisBatch:
         _check(self._L.pvq_analysis_batch_preprocess_device(self._h, _ptr(d_db), n_frames, int(round(frame_time * 1e9)), ft, C.byref(o),
                                                             _stream_handle(stream)))
 
+    def preprocess_pcm(self, vqt: "Vqt", d_pcms, n_frames: int, hop: int, frame_time: Optional[float] = None, outputs: Optional[dict] = None,
+                       max_peaks: int = 0, n_leads=None, d_db=None, stream=None) -> None:
+        """PCM of every stream -> VQT dB frames -> AnalysisState::preprocess, both stages on the device in one call
+        (pvq_analysis_batch_preprocess_pcm); frame_time defaults to hop / sr.  d_db (optional): [n_streams][n_frames][n_bins] to keep the frames."""
+        if len(d_pcms) != self.n_streams:
+            raise ValueError("one PCM stream per stream of the batch")
+        o = _lib.CAnalysisBatchOutputs()
+        for k, t in (outputs or {}).items():
+            setattr(o, k, _ptr(t))
+        o.max_peaks = max_peaks
+        ptrs = (C.c_void_p * self.n_streams)(*[_ptr(t) for t in d_pcms])
+        nl = (C.c_size_t * self.n_streams)(*[int(x) for x in n_leads]) if n_leads is not None else None
+        ft = frame_time if frame_time is not None else hop / vqt.params().sr
+        _check(self._L.pvq_analysis_batch_preprocess_pcm(self._h, vqt._h, ptrs, nl, n_frames, hop, int(round(ft * 1e9)), _ptr(d_db), C.byref(o),
+                                                         _stream_handle(stream)))
+
     def field(self, stream_index: int, name: str) -> np.ndarray:
         out = np.empty(self.n_bins, np.float32)
         _check(self._L.pvq_analysis_batch_get_field(self._h, stream_index, AnalysisBatch._FIELDS[name], out.ctypes.data_as(C.POINTER(C.c_float))))

@@ -21,7 +21,7 @@ EXPORTS = [
     "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_set_workspace_limit", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
     "pvq_analysis_batch_create", "pvq_analysis_batch_destroy", "pvq_analysis_batch_update_vqt_smoothing_duration",
-    "pvq_analysis_batch_preprocess_device", "pvq_analysis_batch_get_field", "pvq_analysis_batch_get_scalars",
+    "pvq_analysis_batch_preprocess_device", "pvq_analysis_batch_preprocess_pcm", "pvq_analysis_batch_get_field", "pvq_analysis_batch_get_scalars",
     "pvq_analysis_state_update_vqt_smoothing_duration", "pvq_analysis_state_preprocess",
     "pvq_analysis_state_bin_to_frequency", "pvq_analysis_state_n_buckets", "pvq_analysis_state_get_field",
     "pvq_analysis_state_get_peaks", "pvq_analysis_state_get_peaks_continuous", "pvq_analysis_state_scene_calmness",
@@ -183,6 +183,9 @@ def load():
     L.pvq_analysis_batch_update_vqt_smoothing_duration.argtypes = [vp, C.c_int, C.c_uint64]; L.pvq_analysis_batch_update_vqt_smoothing_duration.restype = C.c_int
     L.pvq_analysis_batch_preprocess_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(CAnalysisBatchOutputs), vp]
     L.pvq_analysis_batch_preprocess_device.restype = C.c_int
+    L.pvq_analysis_batch_preprocess_pcm.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_uint64, vp,
+                                                    C.POINTER(CAnalysisBatchOutputs), vp]
+    L.pvq_analysis_batch_preprocess_pcm.restype = C.c_int
     L.pvq_analysis_batch_get_field.argtypes = [vp, C.c_uint32, C.c_int, fp]; L.pvq_analysis_batch_get_field.restype = C.c_int
     L.pvq_analysis_batch_get_scalars.argtypes = [vp, C.c_uint32, fp, fp]; L.pvq_analysis_batch_get_scalars.restype = C.c_int
     L.pvq_analysis_state_destroy.argtypes = [vp]

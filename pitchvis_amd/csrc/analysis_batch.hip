@@ -477,6 +477,20 @@ AnalysisBatch::~AnalysisBatch() {
         if (p) (void)hipFree(p);
     if (d_times_) (void)hipFree(d_times_);
     if (d_tab_) (void)hipFree(d_tab_);
+    if (d_frames_) (void)hipFree(d_frames_);
+}
+
+pvq_status AnalysisBatch::frames_buffer(size_t bytes, float** out) {
+    PVQ_HIP(hipSetDevice(device_id_));
+    if (frames_cap_ < bytes) {
+        if (d_frames_) PVQ_HIP(hipFree(d_frames_));   // (synchronises the device: nothing still reads the old buffer)
+        d_frames_ = nullptr;
+        frames_cap_ = 0;
+        PVQ_HIP(hipMalloc(&d_frames_, bytes));
+        frames_cap_ = bytes;
+    }
+    *out = static_cast<float*>(d_frames_);
+    return PVQ_OK;
 }
 
 pvq_status AnalysisBatch::create(int device_id, const VqtRange& range, const FullAnalysisParameters& params, uint32_t n_streams,

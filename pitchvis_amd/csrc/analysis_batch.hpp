@@ -45,6 +45,9 @@ class AnalysisBatch {
     ~AnalysisBatch();
     uint32_t n_streams() const { return n_streams_; }
     uint32_t n_bins() const { return range_.n_buckets(); }
+    const VqtRange& range() const { return range_; }
+    // a grow-only device buffer of the object for the dB frames between the transform and preprocess (pvq_analysis_batch_preprocess_pcm)
+    pvq_status frames_buffer(size_t bytes, float** out);
     int device() const { return device_id_; }
     // analysis.rs:251-270, for every stream
     void update_vqt_smoothing_duration(bool has_duration, Duration d);
@@ -72,6 +75,8 @@ class AnalysisBatch {
     size_t times_cap_ = 0;
     void* d_tab_ = nullptr;            // EMA weights of the running call (host libm), then the frames' row indices
     size_t tab_cap_ = 0;
+    void* d_frames_ = nullptr;         // dB frames of pvq_analysis_batch_preprocess_pcm
+    size_t frames_cap_ = 0;
     std::vector<float> tab_host_;      // what d_tab_ holds (constant frame time: reused by the next call without an upload)
 };
 

@@ -646,6 +646,37 @@ pvq_status pvq_analysis_batch_preprocess_device(pvq_analysis_batch* b, const flo
         return b->impl->preprocess_device(d_db, n_frames, pvq::Duration{frame_time_ns}, frame_times_ns, o, static_cast<hipStream_t>(stream));
     } catch (...) { return translate_exception(); }
 }
+pvq_status pvq_analysis_batch_preprocess_pcm(pvq_analysis_batch* b, pvq_vqt* v, const float* const* d_pcm, const size_t* n_lead, size_t n_frames,
+                                             size_t hop, uint64_t frame_time_ns, float* d_db, const pvq_analysis_batch_outputs* outs, void* stream) {
+    try {
+        if (!b || !v) return null_handle();
+        const pvq::VqtRange& r = v->impl->params().range;
+        if (b->impl->device() != v->impl->device() || b->impl->n_bins() != v->impl->n_bins() || b->impl->range().min_freq != r.min_freq ||
+            b->impl->range().buckets_per_octave != r.buckets_per_octave) {
+            pvq::set_last_error("the transform handle and the analysis batch must sit on the same device and share the VqtRange");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        if (n_frames == 0) return PVQ_OK;
+        const uint32_t ns = b->impl->n_streams();
+        float* db = d_db;
+        if (!db) {
+            pvq_status st = b->impl->frames_buffer((size_t)ns * n_frames * b->impl->n_bins() * sizeof(float), &db);
+            if (st != PVQ_OK) return st;
+        }
+        std::vector<size_t> nf(ns, n_frames);
+        pvq_status st = v->impl->batch_streams_device(d_pcm, n_lead, nf.data(), ns, hop, db, n_frames, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                                      static_cast<hipStream_t>(stream));
+        if (st != PVQ_OK) return st;
+        pvq::AnalysisBatchOutputs o;
+        if (outs) {
+            o.x_vqt_smoothed = outs->x_vqt_smoothed; o.x_vqt_peakfiltered = outs->x_vqt_peakfiltered; o.x_vqt_afterglow = outs->x_vqt_afterglow;
+            o.calmness = outs->calmness; o.pitch_accuracy = outs->pitch_accuracy; o.pitch_deviation = outs->pitch_deviation;
+            o.peak_mask = outs->peak_mask; o.peak_count = outs->peak_count; o.center = outs->center; o.size = outs->size;
+            o.max_peaks = outs->max_peaks; o.scene_calmness = outs->scene_calmness; o.tuning_grid_inaccuracy = outs->tuning_grid_inaccuracy;
+        }
+        return b->impl->preprocess_device(db, n_frames, pvq::Duration{frame_time_ns}, nullptr, o, static_cast<hipStream_t>(stream));
+    } catch (...) { return translate_exception(); }
+}
 pvq_status pvq_analysis_batch_get_field(pvq_analysis_batch* b, uint32_t stream_index, pvq_analysis_field f, float* out) {
     try {
         if (!b) return null_handle();

@@ -152,6 +152,34 @@ def test_streams_feed_the_analysis_batch_on_the_device():
     assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0]) and int(outs[0]["peak_count"].sum()) > 0
 
 
+def test_pcm_to_analysis_in_one_call():
+    """pvq_analysis_batch_preprocess_pcm: the consumers' loop (update_vqt -> AnalysisState::preprocess per analysis) for many streams in
+    one call == the two calls it is made of, and the batch object's own frame buffer == a caller's"""
+    pp, _ = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    hop, n, nf = 800, 10, 150     # the viewer's 60 analyses per second at 48 kHz
+    pcms = _streams(n, hop, [nf] * n, [0] * n, 6000)
+    keys = dict(x_vqt_smoothed=(n, nf, v.n_bins), calmness=(n, nf, v.n_bins), scene_calmness=(n, nf))
+    def outs():
+        o = {k: torch.zeros(shape, device="cuda") for k, shape in keys.items()}
+        o["peak_count"] = torch.zeros((n, nf), dtype=torch.int32, device="cuda")
+        o["center"] = torch.zeros((n, nf, 32), device="cuda"); o["size"] = torch.zeros((n, nf, 32), device="cuda")
+        return o
+    a, b, c = outs(), outs(), outs()
+    d_db = torch.empty((n, nf, v.n_bins), device="cuda")
+    v.batch_streams_device(pcms, hop, [nf] * n, d_db, nf)
+    P.AnalysisBatch(pp.range, n).preprocess_device(d_db, nf, hop / 48000.0, a, max_peaks=32)
+    P.AnalysisBatch(pp.range, n).preprocess_pcm(v, pcms, nf, hop, outputs=b, max_peaks=32)
+    kept = torch.empty_like(d_db)
+    P.AnalysisBatch(pp.range, n).preprocess_pcm(v, pcms, nf, hop, outputs=c, max_peaks=32, d_db=kept)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, d_db) and int(a["peak_count"].sum()) > 0
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    with pytest.raises(P.PvqError):   # another range
+        P.AnalysisBatch(P.VqtRange(55.0, 6, 36), n).preprocess_pcm(v, pcms, nf, hop)
+
+
 def test_streams_argument_checks():
     pp, _ = get_geom("bench_48k_252")
     v = P.Vqt.new(pp, 0)
