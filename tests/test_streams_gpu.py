@@ -202,3 +202,33 @@ def test_streams_argument_checks():
     v.calculate_batch_db_device(pcms[0], 256, 64, ref)
     torch.cuda.synchronize()
     assert torch.equal(d_db[0], ref)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_streams_fuzz_bit_identical_to_single_calls(seed):
+    """seeded random batches — geometry, hop (power-of-two, general, interleaved-grid and FFT-path hops), stream count, ragged
+    lengths from 0 to a few thousand frames (short streams are staged, long ones run as segments of their own), leads, output
+    stride, workspace limit — every one bit for bit what stream-by-stream calls give"""
+    rng = np.random.default_rng(9000 + seed)
+    name, hops = [("bench_48k_252", (256, 512, 128, 1600, 800, 320, 735)), ("serial_22k_180", (256, 64, 1024, 704, 735)),
+                  ("hires_96k_360", (128, 256, 3200, 1000)), ("default_22k_588", (256, 1344, 2048, 367))][seed % 4]
+    hop = int(hops[int(rng.integers(0, len(hops)))])
+    pp, _ = get_geom(name)
+    v = P.Vqt.new(pp, 0)
+    n = int(rng.integers(1, 28))
+    big = 1 + int(rng.integers(0, 3))   # a few streams beyond the staging threshold
+    frames = []
+    for s in range(n):
+        kind = rng.integers(0, 10)
+        if kind == 0: frames.append(0)
+        elif kind == 1: frames.append(int(rng.integers(1, 5)))
+        elif kind == 2 and big > 0 and hop <= 512:
+            frames.append(int(rng.integers(2049, 3500)))
+            big -= 1
+        else: frames.append(int(rng.integers(5, 700)))
+    leads = [int(rng.integers(0, 2 * v.window_union)) if rng.integers(0, 2) else 0 for _ in range(n)]
+    stride = max(frames + [1]) + int(rng.integers(0, 3)) * 17
+    if rng.integers(0, 3) == 0:
+        v.set_workspace_limit(int(rng.integers(8, 64)) << 20)
+    pcms = _streams(n, hop, frames, leads, 7000 + 50 * seed)
+    _check_equal(v, pcms, hop, frames, leads, stride=stride, max_peaks=int(rng.integers(1, 70)))
