@@ -8,7 +8,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PVQ_DEV_LIB=1 selects the developer build of the same sources (libpvq_dev.so, -DPVQ_DEV_KNOBS: it alone reads the PVQ_* environment
 # knobs that the tile-shape / fallback tests, the A/B scripts and the phase-stamp tools use).  The product library reads no environment.
-LIB_PATH = os.path.join(_HERE, "lib", "libpvq_dev.so" if os.environ.get("PVQ_DEV_LIB") == "1" else "libpvq.so")
+# PVQ_DEV_LIB=<name> (anything else) selects lib/libpvq_<name>.so: a developer build of OTHER sources kept beside it for a same-box A/B of two
+# code versions (scripts/dev_ab_knob.py PVQ_DEV_LIB 1,<name>); such files are never committed or shipped.
+_dev = os.environ.get("PVQ_DEV_LIB", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libpvq.so" if not _dev else ("libpvq_dev.so" if _dev == "1" else "libpvq_%s.so" % _dev))
 
 # every symbol include/pvq.h declares
 EXPORTS = [
