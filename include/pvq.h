@@ -156,12 +156,18 @@ typedef enum pvq_algo {
                             * share it.  Takes a power-of-two hop (>= 64) that divides every window (doubling tree); a multiple of 64 that
                             * the longest window holds at most 16 times, e.g. 1 600 (whole blocks + the window's remainder, Horner combine);
                             * or a hop whose 2-, 4-, 8- or 16-fold is one of those, e.g. 800 or 320 (that many interleaved block grids).
-                            * PVQ_ALGO_AUTO picks it whenever it applies and the batch has >= 64 frames per grid; forcing it on another hop
+                            * PVQ_ALGO_AUTO picks it where it applies and pays (pvq_vqt_resolve_algo); forcing it on another hop
                             * (735, say) returns PVQ_ERR_UNSUPPORTED */
 } pvq_algo;
 pvq_status pvq_vqt_set_algo(pvq_vqt *v, pvq_algo algo);
 /* which algorithm the last batch call actually used */
 pvq_algo pvq_vqt_last_algo(const pvq_vqt *v);
+/* which algorithm a batch of n_frames frames (all streams of a *_streams call together) at this hop takes under the current setting.
+ * PVQ_ALGO_AUTO takes the block-DFT path where it applies and is the faster one: from 64 frames on for a power-of-two hop; for a
+ * general hop (1 600, 800 ...) from where its launch floor — a K loop hop / 2 deep per tile — is paid back, ~1 700 frames at
+ * 48 kHz / 252 bins / hop 1 600 (smaller batches: the FFT path, a workgroup per frame).  The two paths agree to the parity bars, not
+ * bit for bit: a caller that needs the same bits for every batch size fixes the path with pvq_vqt_set_algo. */
+pvq_algo pvq_vqt_resolve_algo(pvq_vqt *v, size_t hop, size_t n_frames);
 
 /* arithmetic of the block-DFT GEMM and kernel product (default PVQ_GEMM_F32).  Both accumulate in fp32 and meet the
  * same parity bars; PVQ_GEMM_BF16X3 writes each fp32 operand exactly as three bf16 terms and uses the bf16 matrix

@@ -420,6 +420,10 @@ class Vqt:
     def last_algo(self) -> int:
         return self._L.pvq_vqt_last_algo(self._h)
 
+    def resolve_algo(self, hop: int, n_frames: int) -> int:
+        """the path a batch of n_frames frames at this hop takes under the current setting (pvq_vqt_resolve_algo)"""
+        return self._L.pvq_vqt_resolve_algo(self._h, hop, n_frames)
+
     def set_profiling(self, on) -> None:
         """False / True: HIP events around every kernel launch; 2: only around the transform's main kernel"""
         _check(self._L.pvq_vqt_set_profiling(self._h, 2 if on == 2 else (1 if on else 0)))

@@ -19,7 +19,7 @@ EXPORTS = [
     "pvq_vqt_destroy", "pvq_vqt_get_params", "pvq_vqt_n_bins", "pvq_vqt_delay_seconds", "pvq_vqt_window_union",
     "pvq_vqt_n_groups", "pvq_vqt_group_info", "pvq_vqt_group_csr", "pvq_vqt_filter_params",
     "pvq_vqt_calculate_instant_db", "pvq_vqt_calculate_batch_db", "pvq_vqt_calculate_batch_db_device",
-    "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
+    "pvq_vqt_set_algo", "pvq_vqt_last_algo", "pvq_vqt_resolve_algo", "pvq_analysis_default_params", "pvq_analyze_batch_device",
     "pvq_analyze_batch", "pvq_vqt_analyze_batch_device", "pvq_vqt_calculate_batch_db_streams", "pvq_vqt_analyze_batch_streams", "pvq_plan_shard", "pvq_vqt_analyze_batch_multi", "pvq_vqt_set_profiling", "pvq_vqt_last_kernel_ms",
     "pvq_vqt_kernel_name", "pvq_vqt_last_kernel_launches", "pvq_vqt_last_frames_per_launch", "pvq_vqt_set_gemm_precision", "pvq_vqt_set_workspace_limit", "pvq_vqt_blockdft_columns", "pvq_vqt_set_twiddle_fp16",
     "pvq_analysis_full_default_params", "pvq_analysis_state_create", "pvq_analysis_state_destroy",
@@ -151,6 +151,7 @@ def load():
     L.pvq_vqt_calculate_batch_db_device.restype = C.c_int
     L.pvq_vqt_set_algo.argtypes = [vp, C.c_int]; L.pvq_vqt_set_algo.restype = C.c_int
     L.pvq_vqt_last_algo.argtypes = [vp]; L.pvq_vqt_last_algo.restype = C.c_int
+    L.pvq_vqt_resolve_algo.argtypes = [vp, C.c_size_t, C.c_size_t]; L.pvq_vqt_resolve_algo.restype = C.c_int
     L.pvq_vqt_blockdft_columns.argtypes = [vp]; L.pvq_vqt_blockdft_columns.restype = C.c_uint32
     L.pvq_vqt_set_gemm_precision.argtypes = [vp, C.c_int]; L.pvq_vqt_set_gemm_precision.restype = C.c_int
     L.pvq_vqt_set_workspace_limit.argtypes = [vp, C.c_uint64]; L.pvq_vqt_set_workspace_limit.restype = C.c_int

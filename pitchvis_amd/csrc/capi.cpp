@@ -329,6 +329,12 @@ pvq_algo pvq_vqt_last_algo(const pvq_vqt* v) {
         return v ? v->impl->last_algo() : PVQ_ALGO_AUTO;
     } catch (...) { (void)translate_exception(); return PVQ_ALGO_AUTO; }
 }
+pvq_algo pvq_vqt_resolve_algo(pvq_vqt* v, size_t hop, size_t n_frames) {
+    try {
+        if (!v || hop == 0) return PVQ_ALGO_AUTO;
+        return v->impl->resolve_algo(hop, n_frames);
+    } catch (...) { (void)translate_exception(); return PVQ_ALGO_AUTO; }
+}
 
 pvq_status pvq_vqt_set_twiddle_fp16(pvq_vqt* v, int enable) {
     try {

@@ -998,7 +998,7 @@ pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t 
         }
         use_block = true;
     } else if (algo_ == PVQ_ALGO_AUTO) {
-        use_block = r != 0 && n_frames >= 64 * r;
+        use_block = r != 0 && n_frames >= auto_block_min_frames(hop, r);
     }
     if (use_block && r > 1 && !blockdft_takes_streams(hop * r)) {
         if (algo_ == PVQ_ALGO_BLOCKDFT) {
@@ -1024,7 +1024,39 @@ pvq_algo Vqt::resolve_algo(size_t hop, size_t n_frames) {
     const size_t r = blockdft_hop_factor(hop);
     if (r == 0 || (r > 1 && !blockdft_takes_streams(hop * r))) return algo_ == PVQ_ALGO_BLOCKDFT ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;   // (forced: run_batch reports the error)
     if (algo_ == PVQ_ALGO_BLOCKDFT) return PVQ_ALGO_BLOCKDFT;
-    return n_frames >= 64 * r ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;
+    return n_frames >= auto_block_min_frames(hop, r) ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;
+}
+
+// From how many frames on PVQ_ALGO_AUTO takes the block-DFT path (hop * r its block length).  A power-of-two hop: one tile row per
+// grid (the two paths cost the same 60-70 us there and the block path pulls away from ~500 frames on).  A general hop is different:
+// its tiles' K loops are hop * r / 2 deep, so a launch cannot end before ~180 us at 1 600 samples and ~300 us at 3 200 however few
+// frames it holds, while the FFT path — a workgroup per frame, 512 of them side by side — takes 53 us for up to ~420 frames and
+// 0.125 us per frame beyond (48 kHz / 252 bins; profiles/r04_small_batches.txt: 64 frames at hop 800 took 367 us on the block path
+// against 64 on the FFT path).  The estimate below — both paths' time as floor + frames x slope, the slopes scaled by the geometry's
+// FFT work and column count — puts the switch where the two lines cross: ~1 700 frames at hop 800 / 1 600, ~3 500 at 3 200.
+size_t Vqt::auto_block_min_frames(size_t hop, size_t r) const {
+    const size_t hop_eff = hop * r;
+    bool divides = (hop_eff & (hop_eff - 1)) == 0;
+    double fft_work = 0.0;   // sum over the window groups of W log2 W
+    size_t cols = 0;         // spectrum columns the kernel reads (upper bound: every group's highest column)
+    for (const WindowGroup& g : plan_.kernel.window_groups) {
+        const size_t w = g.window_size();
+        divides = divides && w % hop_eff == 0;
+        fft_work += (double)w * std::log2((double)w);
+        uint32_t top = 0;
+        for (uint32_t c : g.filter_bank.col_idx) top = c > top ? c : top;
+        for (uint32_t c : g.negative_filter_bank.col_idx) top = c > top ? c : top;
+        cols += top + 1;
+    }
+    if (divides) return 64 * r;
+    double t_fft = 3.0e-7 * fft_work;                                                     // us per frame, FFT path at scale
+    if (plan_.params.n_fft > 0 && fft_work > 6.0e5) t_fft *= 1.35;                        // (a 32 768-sample window: 1 024 threads per frame, one workgroup per CU)
+    const double floor_block = 58.0 + 0.075 * ((double)hop_eff - 256.0) + 18.0;           // us: shortest launch pair of the general-hop kernels
+    const double t_block = (1.2e-5 * (double)hop_eff + 0.0015) * ((double)cols / 871.0);  // us per frame (871: the bound at 48 kHz / 252 bins, 602 of them read)
+    if (t_fft <= t_block) return 64 * r;   // (does not happen for hops the path takes: <= 4 096 samples)
+    const double n = floor_block / (t_fft - t_block);
+    const size_t lo = 64 * r;
+    return n < (double)lo ? lo : (size_t)n;
 }
 
 size_t Vqt::blockdft_hop_factor(size_t hop) const {
@@ -1089,7 +1121,7 @@ pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_
         }
         use_block = true;
     } else if (algo_ == PVQ_ALGO_AUTO) {
-        use_block = r != 0 && total >= 64 * r && (r == 1 || blockdft_takes_streams(hop * r));
+        use_block = r != 0 && total >= auto_block_min_frames(hop, r) && (r == 1 || blockdft_takes_streams(hop * r));
     }
     if (use_block && blockdft_takes_streams(hop * r)) {
         // SHORT streams are staged one behind the other into ONE buffer — each in a slot of whole 64 r-frame tiles, the zeroed gap behind

@@ -144,6 +144,7 @@ class Vqt {
         uint64_t slot_hash = 0;
     };
     size_t blockdft_hop_factor(size_t hop) const;   // smallest r in {1, 2, 4, 8, 16} with blockdft_applicable(r * hop), 0 if none
+    size_t auto_block_min_frames(size_t hop, size_t r) const;   // PVQ_ALGO_AUTO: the block-DFT path from this many frames on
     pvq_status launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t hop, float* d_out_db, float* d_out_cplx, size_t rows_total,
                                        const PeakParamsDev* pk, hipStream_t stream);
     pvq_status prepare_blockdft(size_t hop);

@@ -174,10 +174,19 @@ def test_blockdft_general_hops_vs_oracle(name, hop, nf):
         assert v.last_algo() == algo_id
         wdb, wcx = ov.calculate_batch(pcm, hop, nf, n_lead=n_lead, want_complex=True)
         assert_parity(db, cx, wdb, wcx, xpeak=input_peak(pcm, hop, nf, n_lead, v.window_union), sr=op.sr)
-    # ALGO_AUTO takes the same path for such a hop
+    # ALGO_AUTO takes this path for such a hop once the batch pays its launch floor back (a general hop's K loops are hop / 2 deep: a
+    # few hundred frames are faster on the FFT path), and says beforehand which: the same bits as the forced call either way
     _set_algo(v, P.ALGO_AUTO)
+    assert v.resolve_algo(hop, 64) in (P.ALGO_FFT, P.ALGO_BLOCKDFT) and v.resolve_algo(hop, 1 << 20) == P.ALGO_BLOCKDFT
+    want_algo = v.resolve_algo(hop, nf)
     db2, cx2 = run_gpu(v, pcm, hop, nf, n_lead)
-    assert v.last_algo() == P.ALGO_BLOCKDFT and np.array_equal(db2, db)
+    assert v.last_algo() == want_algo
+    if want_algo == P.ALGO_BLOCKDFT:
+        assert np.array_equal(db2, db)
+    else:
+        _set_algo(v, P.ALGO_FFT)
+        db3, _ = run_gpu(v, pcm, hop, nf, n_lead)
+        assert np.array_equal(db2, db3)
     # a hop with no such multiple (735 = pitchvis_serial's 1 / 30 s at 22 050 Hz: odd) stays on the FFT path, and says so when forced
     _set_algo(v, P.ALGO_BLOCKDFT)
     with pytest.raises(P.PvqError) as e:

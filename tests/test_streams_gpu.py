@@ -75,8 +75,13 @@ def test_streams_equal_single_stream_calls_bit_for_bit(name, hop):
     frames = [700, 64, 1, 300, 0, 257, 130, 999]          # ragged, one empty stream, one of a single frame
     leads = [0, 5000, 0, v.window_union - hop, 0, 123, 40000, 0]   # stream starts, shard halos, odd leads
     pcms = _streams(len(frames), hop, frames, leads, 1000)
+    v.set_algo(P.ALGO_BLOCKDFT)   # (left to itself ALGO_AUTO sends 2 451 frames at a general hop to the path pvq_vqt_resolve_algo names: below)
     _check_equal(v, pcms, hop, frames, leads, stride=1024)
     assert v.last_algo() == P.ALGO_BLOCKDFT
+    want = v.resolve_algo(hop, sum(frames))
+    assert want == P.ALGO_BLOCKDFT or (hop & (hop - 1)) != 0
+    _check_equal(v, pcms, hop, frames, leads, stride=1024)
+    assert v.last_algo() == want
 
 
 def test_streams_uniform_lengths_and_both_arithmetics():
