@@ -2572,18 +2572,29 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             fa.n_groups = t->n_groups;
             static const int dyn_lds_env = dev_knob("PVQ_DYN_LDS", 0);      // extra LDS -> one workgroup per CU
             static const int bm_env = dev_knob("PVQ_FUSED_BM", 0);          // 128: 128-row tiles (the tile-shape bit-identity test)
-            // 256-row tiles: 257 - Nb complete frames per tile (1.08x row recomputation instead of 1.2x with 128 rows)
-            const int fused_bm = bm_env == 128 && !use_bf ? 128 : 256;
-            double eff_tiles = 0.0;   // matrix work of the launch in whole-tile units
-            for (const auto& k : segs)
-                for (int g = 0; g < t->n_groups; ++g) {
-                    const int S = fused_bm - t->groups[g].nb_f + 1;
-                    const int rows_g = k.nf + t->groups[g].nb - t->groups[g].nb_f;
-                    // a last tile of at most 16 columns runs half the MFMAs (fp32 kernel; the few tiles at the stream's ends run the full
-                    // loop: counted as half all the same)
-                    const bool half_last = !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
-                    eff_tiles += (t->groups[g].n_tiles - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
-                }
+            // matrix work of the launch in whole-tile units, for tiles of bm rows
+            auto count_tiles = [&](int bm) {
+                double n = 0.0;
+                for (const auto& k : segs)
+                    for (int g = 0; g < t->n_groups; ++g) {
+                        const int S = bm - t->groups[g].nb_f + 1;
+                        const int rows_g = k.nf + t->groups[g].nb - t->groups[g].nb_f;
+                        // a last tile of at most 16 columns runs half the MFMAs (fp32 kernel; the few tiles at the stream's ends run the full
+                        // loop: counted as half all the same)
+                        const bool half_last = !use_bf && t->groups[g].n_cols - (t->groups[g].n_tiles - 1) * CB_C <= 16;
+                        n += (t->groups[g].n_tiles - (half_last ? 0.5 : 0.0)) * ((rows_g + S - 1) / S);
+                    }
+                return n;
+            };
+            // 256-row tiles: 257 - Nb complete frames per tile (1.08x row recomputation instead of 1.2x with 128 rows) — for a launch that
+            // fills the chip's 512 workgroup slots a few times over.  A smaller one (fewer than FUSED_SMALL 256-row tiles: up to ~12 000
+            // frames at 48 kHz / 252 bins) takes 128-row tiles: twice the workgroups, each half as long — what such a launch lacks is
+            // parallelism, not efficiency (hop 1 600: 4 096 frames 294 -> 216 us, 8 192: 324 -> 292; hop 256: 2 048 frames 61 -> 54;
+            // profiles/r04_small_tiles.txt).  Same bits either way (a frame's values do not depend on its tile: tests/test_tile_shapes).
+            constexpr double FUSED_SMALL = 1400.0;
+            int fused_bm = 256;
+            if (!use_bf && (bm_env == 128 || (bm_env == 0 && count_tiles(256) < FUSED_SMALL))) fused_bm = 128;
+            double eff_tiles = count_tiles(fused_bm);
             // Frame-stripe tile order: the launch's frames are cut into stripes of 2 048, stripe s belongs to XCD queue s & 7 (workgroup b
             // runs on the XCD of all b' = b mod 8), and a queue takes its stripes in order, within a stripe every group's row tiles with
             // all their column tiles.  All window groups then read a stripe's PCM rows from that XCD's L2 while they are resident (once
@@ -2847,7 +2858,10 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                     ga.gen_kind = kind;
                     ga.stamps = nullptr;
                     ga.clk = nullptr;
-                    hipLaunchKernelGGL(blockdft_gemm_gen<256>, dim3(L->blocks), dim3(512), 0, stream, ga);
+                    if (fused_bm == 256)
+                        hipLaunchKernelGGL(blockdft_gemm_gen<256>, dim3(L->blocks), dim3(512), 0, stream, ga);
+                    else
+                        hipLaunchKernelGGL(blockdft_gemm_gen<128>, dim3(L->blocks), dim3(256), 0, stream, ga);
                     flop += L->eff_flop;
                 }
                 last_gemm_flop_ = flop;

@@ -296,8 +296,9 @@ def test_unfused_fallback_stages_in_a_subprocess():
 def test_tile_shapes_bit_identical_in_subprocesses():
     """Every tile shape of the hop-DFT + tree stage computes the same bits on every test geometry — same sums, same k order, same
     tree levels: a frame's value must not depend on the tile that produced it.  The product (256 rows, neighbouring column tiles
-    paired into 64-column wide tiles except at the stream's ends and in the launch's tail, queues evened out), 128 x 32 rows
-    (PVQ_FUSED_BM=128), 256 x 32 only (PVQ_WIDE=0, unbalanced queues), wide tiles wherever they fit (PVQ_WIDE=2) — knobs of the
+    paired into 64-column wide tiles except at the stream's ends and in the launch's tail, queues evened out; 128 x 32 rows for a
+    launch of fewer than ~1 400 tiles), 128 x 32 rows always (PVQ_FUSED_BM=128), 256 rows always (=256), 256 x 32 only (PVQ_WIDE=0,
+    unbalanced queues), wide tiles wherever they fit (PVQ_WIDE=2) — knobs of the
     developer library libpvq_dev.so — and the product library against the developer one.
     Child processes: the knobs are read once per process."""
     import os, subprocess, sys, textwrap
@@ -325,7 +326,7 @@ def test_tile_shapes_bit_identical_in_subprocesses():
         # other hops on one geometry: 64 (one double k group per tile: the K loops' shortest form), 512 and 1024 (the slice of E is
         # staged in two / four passes; 1024 = the shortest window: no tree level at all in its group)
         pp, op = get_geom("bench_48k_252")
-        for hop in (64, 512, 1024):
+        for hop in (64, 512, 1024, 1600, 800):   # (1 600, 800: the general-hop kernel, blockdft_gemm_gen)
             v = P.Vqt.new(pp, 0)
             v.set_algo(P.ALGO_BLOCKDFT)
             nf, n_lead = 40000 // (hop // 64), 333
@@ -339,14 +340,14 @@ def test_tile_shapes_bit_identical_in_subprocesses():
     """)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     res = {}
-    for tag, env in (("base", {}), ("dev", {"PVQ_DEV_LIB": "1"}), ("bm128", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "128"}),
+    for tag, env in (("base", {}), ("dev", {"PVQ_DEV_LIB": "1"}), ("bm128", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "128"}), ("bm256", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "256"}),
                      ("narrow", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "0", "PVQ_BALANCE": "0"}), ("wide_all", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "2"})):
         f = os.path.join(root, "gpurun_out", f"forms_{tag}.npz")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0 and "FORM_OK" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = dict(np.load(f))
         os.remove(f)
-    for tag in ("dev", "bm128", "narrow", "wide_all"):
+    for tag in ("dev", "bm128", "bm256", "narrow", "wide_all"):
         for k, a in res["base"].items():
             assert np.array_equal(a.view(np.uint32), res[tag][k].view(np.uint32)), (tag, k)
 
