@@ -391,22 +391,32 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
         for (int g = 0; g < a.n_groups; ++g) {
             const GroupDev G = a.groups[g];
             const int N = G.n_cplx;
-            // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]), as a flat float copy; eight loads in flight per thread
+            // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]): one 8-byte load (the stream's samples are 4-byte aligned, whatever the
+            // hop) and one 8-byte LDS store per complex point, eight loads in flight per thread; zeros before the stream start
             {
-                float* Zf = reinterpret_cast<float*>(Z);
+                struct __attribute__((packed, aligned(4))) F2U { float x, y; };
                 const long long s0 = buf0 + G.w0;
-                for (int i0 = tl; i0 < 2 * N; i0 += 8 * T) {
-                    float v[8];
+                for (int n0 = tl; n0 < N; n0 += 8 * T) {
+                    float2 v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int i = i0 + u * T;
-                        const long long sx = s0 + i;
-                        v[u] = (i < 2 * N && sx >= 0 && sx < n_samples) ? pcm[sx] : 0.0f;
+                        const int n = n0 + u * T;
+                        const long long sx = s0 + 2 * n;
+                        v[u] = make_float2(0.0f, 0.0f);
+                        if (n < N) {
+                            if (sx >= 0 && sx + 1 < n_samples) {
+                                const F2U t = *reinterpret_cast<const F2U*>(pcm + sx);
+                                v[u] = make_float2(t.x, t.y);
+                            } else {
+                                if (sx >= 0 && sx < n_samples) v[u].x = pcm[sx];
+                                if (sx + 1 >= 0 && sx + 1 < n_samples) v[u].y = pcm[sx + 1];
+                            }
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int i = i0 + u * T;
-                        if (i < 2 * N) Zf[2 * lpad(i >> 1) + (i & 1)] = v[u];
+                        const int n = n0 + u * T;
+                        if (n < N) Z[lpad(n)] = v[u];
                     }
                 }
             }
