@@ -89,6 +89,11 @@ class WindowExceedsNFft(VqtError):
                          "increase n_fft or gamma, or decrease quality")
 
 
+def last_error() -> str:
+    """the calling thread's last error text (pvq_last_error: thread-local in the library)"""
+    return _lib.load().pvq_last_error().decode()
+
+
 def _check(st: int):
     if st != _lib.PVQ_OK:
         L = _lib.load()

@@ -1,0 +1,92 @@
+"""SURVEY 8b, threading: `Vqt` takes `&mut self` (one caller at a time per instance), instances are independent and live one per
+worker thread (pitchvis_train/src/train.rs:148-154: a `Vqt` per rayon worker), and Bevy calls the viewer's instance from whatever
+scheduler thread runs the system (pitchvis_viewer/src/vqt_system.rs:5-6: a `Resource`, so `Send + Sync`).  The C ABI's promise is
+the same: a handle is not thread-safe, handles are independent.  Here: worker threads with a handle each (different geometries,
+hops and paths) hammer the library at the same time and must reproduce, bit for bit, what the same calls give one after the other;
+a handle made on one thread works on another; error texts stay with the thread that caused them."""
+import threading
+
+import numpy as np
+import pytest
+
+import pitchvis_amd as P
+from helpers import get_geom, white_noise
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+JOBS = [("bench_48k_252", 256, 3000, P.ALGO_AUTO), ("default_22k_588", 256, 1500, P.ALGO_AUTO), ("bench_48k_252", 1600, 2500, P.ALGO_BLOCKDFT),
+        ("serial_22k_180", 735, 400, P.ALGO_AUTO), ("hires_96k_360", 128, 1200, P.ALGO_AUTO), ("bench_48k_288", 800, 700, P.ALGO_FFT)]
+
+
+def _run(v, pcm, hop, nf, rounds):
+    """`rounds` analyze calls on a stream of the caller's own (the buffers are made and read back on that stream too: torch's fills run on
+    its current stream, and nothing orders another stream behind them); every round's outputs"""
+    words = (v.n_bins + 31) // 32
+    st = torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(st):
+        for _ in range(rounds):
+            o = dict(db=torch.empty((nf, v.n_bins), device="cuda"), mask=torch.zeros((nf, words), dtype=torch.int32, device="cuda"),
+                     cnt=torch.zeros(nf, dtype=torch.int32, device="cuda"), ctr=torch.zeros((nf, 48), device="cuda"), sz=torch.zeros((nf, 48), device="cuda"))
+            v.vqt_analyze_batch_device(pcm, hop, nf, o["db"], o["mask"], o["cnt"], o["ctr"], o["sz"], 48, n_lead=123, stream=st)
+            outs.append(o)
+        st.synchronize()
+        return [{k: t.cpu().numpy() for k, t in o.items()} for o in outs]
+
+
+def test_a_handle_per_thread_all_at_once_equals_one_after_the_other():
+    made = []
+    for name, hop, nf, algo in JOBS:
+        pp, _ = get_geom(name)
+        v = P.Vqt.new(pp, 0)          # made on the main thread, used on a worker: handles are not tied to their creating thread
+        v.set_algo(algo)
+        pcm = torch.from_numpy(white_noise(123 + hop * nf, 77 + hop)).cuda()
+        made.append((v, pcm, hop, nf))
+    torch.cuda.synchronize()
+    serial = [_run(v, pcm, hop, nf, 1)[0] for v, pcm, hop, nf in made]
+    results, errors = [None] * len(made), []
+
+    def work(i):
+        try:
+            v, pcm, hop, nf = made[i]
+            results[i] = _run(v, pcm, hop, nf, 6)
+        except Exception as e:   # noqa: BLE001  (handed to the main thread)
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(made))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    for i, rounds in enumerate(results):
+        for o in rounds:
+            for k, a in serial[i].items():
+                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, o[k].view(np.uint32) if o[k].dtype == np.float32 else o[k]), (JOBS[i], k)
+
+
+def test_error_text_stays_with_its_thread():
+    """pvq_last_error is per thread: a failing call on one thread does not overwrite what another thread reads"""
+    pp, _ = get_geom("serial_22k_180")
+    v1, v2 = P.Vqt.new(pp, 0), P.Vqt.new(pp, 0)
+    seen = {}
+
+    def bad():
+        v1.set_algo(P.ALGO_BLOCKDFT)
+        pcm = torch.zeros(735 * 64, device="cuda")
+        db = torch.empty((64, v1.n_bins), device="cuda")
+        try:
+            v1.calculate_batch_db_device(pcm, 735, 64, db)     # no multiple of 735 suits the block-DFT path
+        except P.PvqError as e:
+            seen["bad"] = (e.status, str(e))
+
+    def good():
+        pcm = torch.zeros(256 * 64, device="cuda")
+        db = torch.empty((64, v2.n_bins), device="cuda")
+        v2.calculate_batch_db_device(pcm, 256, 64, db)
+        torch.cuda.synchronize()
+        seen["good"] = P.last_error() if hasattr(P, "last_error") else ""
+
+    t1 = threading.Thread(target=bad); t1.start(); t1.join()
+    t2 = threading.Thread(target=good); t2.start(); t2.join()
+    assert seen["bad"][0] == 7 and "block-DFT" in seen["bad"][1]
+    assert "block-DFT" not in seen["good"]
