@@ -1,4 +1,4 @@
-"""SURVEY 8b, threading: `Vqt` takes `&mut self` (one caller at a time per instance), instances are independent and live one per
+"""SURVEY 8b, ownership and threading: `Vqt` takes `&mut self` (one caller at a time per instance), instances are independent and live one per
 worker thread (pitchvis_train/src/train.rs:148-154: a `Vqt` per rayon worker), and Bevy calls the viewer's instance from whatever
 scheduler thread runs the system (pitchvis_viewer/src/vqt_system.rs:5-6: a `Resource`, so `Send + Sync`).  The C ABI's promise is
 the same: a handle is not thread-safe, handles are independent.  Here: worker threads with a handle each (different geometries,
@@ -90,3 +90,38 @@ def test_error_text_stays_with_its_thread():
     t2 = threading.Thread(target=good); t2.start(); t2.join()
     assert seen["bad"][0] == 7 and "block-DFT" in seen["bad"][1]
     assert "block-DFT" not in seen["good"]
+
+
+def test_handles_swapped_wholesale_do_not_leak_device_memory():
+    """the viewer replaces its `Vqt` at run time when the parameters change (pitchvis_viewer/src/app/common.rs:1130-1133: the old one
+    is dropped): create -> use on every path (power-of-two hop, general hop, FFT path, a staged many-streams call, the device
+    `AnalysisState` batch) -> destroy, thirty times over; the device's free memory afterwards is what it was after the first
+    round (workspaces, tile lists, tables, shard buffers and streams all go with the handle)"""
+    import gc
+    pp, _ = get_geom("bench_48k_252")
+
+    def one_round():
+        v = P.Vqt.new(pp, 0)
+        nf = 3000
+        pcm = torch.from_numpy(white_noise(1600 * nf, 5)).cuda()
+        db = torch.empty((nf, v.n_bins), device="cuda")
+        for hop, algo in ((256, P.ALGO_AUTO), (1600, P.ALGO_BLOCKDFT), (735, P.ALGO_AUTO)):
+            v.set_algo(algo)
+            v.calculate_batch_db_device(pcm, hop, nf, db)
+        v.set_algo(P.ALGO_AUTO)
+        sdb = torch.empty((6, 500, v.n_bins), device="cuda")
+        v.batch_streams_device([pcm[i * 200000: i * 200000 + 256 * 500] for i in range(6)], 256, [500] * 6, sdb)
+        ab = P.AnalysisBatch(P.VqtRange(55.0, 7, 36), n_streams=6)
+        ab.preprocess_device(sdb, 500, frame_time=256 / 48000.0)
+        torch.cuda.synchronize()
+        v.input_status()
+        del ab, v, pcm, db, sdb
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    first = one_round()
+    for _ in range(29):
+        last = one_round()
+    assert first - last < (8 << 20), f"free device memory fell by {(first - last) / 2**20:.1f} MiB over 29 create / use / destroy rounds"
