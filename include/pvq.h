@@ -163,7 +163,7 @@ pvq_status pvq_vqt_set_algo(pvq_vqt *v, pvq_algo algo);
 /* which algorithm the last batch call actually used */
 pvq_algo pvq_vqt_last_algo(const pvq_vqt *v);
 /* which algorithm a batch of n_frames frames (all streams of a *_streams call together) at this hop takes under the current setting.
- * PVQ_ALGO_AUTO takes the block-DFT path where it applies and is the faster one: from 64 frames on for a power-of-two hop; for a
+ * PVQ_ALGO_AUTO takes the block-DFT path where it applies and is the faster one: from 384 frames on for a power-of-two hop; for a
  * general hop (1 600, 800 ...) from where its launch floor — a K loop hop / 2 deep per tile — is paid back, ~1 700 frames at
  * 48 kHz / 252 bins / hop 1 600 (smaller batches: the FFT path, a workgroup per frame).  The two paths agree to the parity bars, not
  * bit for bit: a caller that needs the same bits for every batch size fixes the path with pvq_vqt_set_algo. */

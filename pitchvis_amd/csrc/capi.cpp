@@ -32,8 +32,14 @@ struct pvq_mono_agc {
 // buffer (4 x buf_size) runs out
 struct pvq_stream {
     ~pvq_stream() {   // also runs when pvq_stream_create fails half way: no device buffer is leaked
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
         if (d_ring) (void)hipFree(d_ring);
         if (d_db) (void)hipFree(d_db);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
     }
     pvq_vqt* vqt = nullptr;
     size_t buf_size = 0, cap = 0, w = 0;
@@ -43,7 +49,12 @@ struct pvq_stream {
     pvq::MonoAgc agc{0.07f, 0.0001f};   // audio_desktop.rs:93
     float gain = 0.0f;                  // audio_desktop.rs:83
     float chunk_size_ms = 0.0f;
-    std::vector<float> staging;
+    // page-locked staging and a stream of the object's own: a push is one asynchronous DMA behind the conditioning on the host, a frame
+    // the kernels + one asynchronous copy back + ONE wait (pageable buffers cost a staged, synchronous copy each way)
+    hipStream_t stream = nullptr;
+    float* h_in = nullptr;    // [buf_size]: the chunk being appended
+    float* h_out = nullptr;   // [n_bins]
+    bool in_flight = false;   // h_in is being read by a copy queued on `stream`
 };
 
 namespace {
@@ -863,7 +874,11 @@ pvq_status pvq_stream_create(pvq_vqt* v, size_t buf_size, int with_agc, pvq_stre
         PVQ_CAPI_HIP(hipSetDevice(v->impl->device()));
         PVQ_CAPI_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_ring), s->cap * sizeof(float)));
         PVQ_CAPI_HIP(hipMemset(s->d_ring, 0, s->cap * sizeof(float)));
+        PVQ_CAPI_HIP(hipStreamSynchronize(nullptr));   // (the object's own stream does not wait for the null stream)
         PVQ_CAPI_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_db), v->impl->n_bins() * sizeof(float)));
+        PVQ_CAPI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        PVQ_CAPI_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_in), buf_size * sizeof(float), hipHostMallocDefault));
+        PVQ_CAPI_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_out), v->impl->n_bins() * sizeof(float), hipHostMallocDefault));
         s->w = buf_size;
         *out = s.release();
         return PVQ_OK;
@@ -884,20 +899,25 @@ pvq_status pvq_stream_push(pvq_stream* s, const float* data, size_t n) {
             pvq::set_last_error("chunk longer than the ring buffer");
             return PVQ_ERR_BAD_LENGTH;
         }
-        s->staging.assign(data, data + n);
+        PVQ_CAPI_HIP(hipSetDevice(s->vqt->impl->device()));
+        if (s->in_flight) {   // a second push before the previous one's copy was waited for (no frame in between)
+            PVQ_CAPI_HIP(hipStreamSynchronize(s->stream));
+            s->in_flight = false;
+        }
+        std::copy(data, data + n, s->h_in);
         if (s->with_agc) {
             float sq = 0.0f;
             for (size_t i = 0; i < n; ++i) sq += data[i] * data[i];     // audio_desktop.rs:101
             s->agc.freeze_gain(sq < 1e-6f);                             // :102
-            s->agc.process(s->staging.data(), n);                       // :111 (over the newest samples of the ring)
+            s->agc.process(s->h_in, n);                                 // :111 (over the newest samples of the ring)
             s->gain = s->agc.gain();                                    // :112
         }
-        PVQ_CAPI_HIP(hipSetDevice(s->vqt->impl->device()));
         if (s->w + n > s->cap) {   // compact: newest buf_size samples to the front (ranges do not overlap: cap = 4 buf_size)
-            PVQ_CAPI_HIP(hipMemcpy(s->d_ring, s->d_ring + s->w - s->buf_size, s->buf_size * sizeof(float), hipMemcpyDeviceToDevice));
+            PVQ_CAPI_HIP(hipMemcpyAsync(s->d_ring, s->d_ring + s->w - s->buf_size, s->buf_size * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
             s->w = s->buf_size;
         }
-        PVQ_CAPI_HIP(hipMemcpy(s->d_ring + s->w, s->staging.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        PVQ_CAPI_HIP(hipMemcpyAsync(s->d_ring + s->w, s->h_in, n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        s->in_flight = true;
         s->w += n;
         s->chunk_size_ms = static_cast<float>(n) / s->vqt->impl->params().sr * 1000.0f;   // :118
         return PVQ_OK;
@@ -918,9 +938,13 @@ pvq_status pvq_stream_frame_db(pvq_stream* s, float* out_db) {
         if (!s || !out_db) return null_handle();
         const size_t n_fft = s->vqt->impl->params().n_fft;
         // one frame over the newest n_fft samples: n_lead = n_fft - 1 samples of history + a hop of 1
-        pvq_status st = s->vqt->impl->calculate_batch_db_device(s->d_ring + s->w - n_fft, n_fft - 1, 1, 1, s->d_db, nullptr, nullptr);
+        pvq_status st = s->vqt->impl->calculate_batch_db_device(s->d_ring + s->w - n_fft, n_fft - 1, 1, 1, s->d_db, nullptr, s->stream);
         if (st != PVQ_OK) return st;
-        PVQ_CAPI_HIP(hipMemcpy(out_db, s->d_db, s->vqt->impl->n_bins() * sizeof(float), hipMemcpyDeviceToHost));
+        const size_t nb = s->vqt->impl->n_bins();
+        PVQ_CAPI_HIP(hipMemcpyAsync(s->h_out, s->d_db, nb * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        PVQ_CAPI_HIP(hipStreamSynchronize(s->stream));
+        s->in_flight = false;
+        std::copy(s->h_out, s->h_out + nb, out_db);
         return PVQ_OK;
     } catch (...) { return translate_exception(); }
 }
@@ -932,6 +956,8 @@ pvq_status pvq_stream_read(pvq_stream* s, float* out, size_t n_last) {
             return PVQ_ERR_BAD_LENGTH;
         }
         PVQ_CAPI_HIP(hipSetDevice(s->vqt->impl->device()));
+        PVQ_CAPI_HIP(hipStreamSynchronize(s->stream));   // the appends queued on the object's stream
+        s->in_flight = false;
         PVQ_CAPI_HIP(hipMemcpy(out, s->d_ring + s->w - n_last, n_last * sizeof(float), hipMemcpyDeviceToHost));
         return PVQ_OK;
     } catch (...) { return translate_exception(); }

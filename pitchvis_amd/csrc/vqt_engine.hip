@@ -346,6 +346,11 @@ struct FftArgs {
     float2* out_cplx;
     unsigned* status;
     int dev_skip;   // developer knob PVQ_FFT_SKIP (timing experiments, wrong results): 1 skips the row dots, 2 the FFT passes
+    // Few frames (the streaming front end's single frame, short clips): one workgroup per (frames of a workgroup, WINDOW GROUP) instead
+    // of one walking the groups in turn — a frame's latency is then its longest group's (the 16 384-sample window: ~55 % of the
+    // walk), not their sum; x_vqt goes through xv_split ([frame][bin], complex) and db_rows finishes the frames.  Same arithmetic
+    // per group, same dB routine: same bits as the walk.
+    float2* xv_split;   // nullptr: every workgroup walks all groups
 };
 
 // T threads per frame, F = BLOCK / T frames per workgroup side by side: a 4096-sample window is a 2048-point complex FFT =
@@ -366,7 +371,11 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
     float2* xv = Z + zlen;
     float* red = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem) + (size_t)F * per_frame) + fl * 2 * (T / 64);
 
-    for (int fg = blockIdx.x; fg * F < a.n_frames; fg += gridDim.x) {
+    // (split: every frame's largest window first, then the next — workgroups start in index order, the long ones must not come last)
+    const int fg_step = a.xv_split ? (int)(gridDim.x / a.n_groups) : (int)gridDim.x;
+    const int g_only = a.xv_split ? (int)(blockIdx.x / fg_step) : -1;
+    const int fg0 = a.xv_split ? (int)(blockIdx.x % fg_step) : (int)blockIdx.x;
+    for (int fg = fg0; fg * F < a.n_frames; fg += fg_step) {
         const bool live = fg * F + fl < a.n_frames;
         const int gframe = live ? fg * F + fl : a.n_frames - 1;   // a padding frame repeats the last one and stores nothing
         // the frame's stream (wave-uniform: T >= 64 threads share a frame)
@@ -389,6 +398,7 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
         const long long buf0 = n_lead + (frame + 1) * a.hop - a.n_fft;
 
         for (int g = 0; g < a.n_groups; ++g) {
+            if (g_only >= 0 && g != g_only) continue;   // (uniform)
             const GroupDev G = a.groups[g];
             const int N = G.n_cplx;
             // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]): one 8-byte load (the stream's samples are 4-byte aligned, whatever the
@@ -485,12 +495,32 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
             }
             __syncthreads();   // the next group's gather overwrites the spectrum columns
         }
+        if (g_only >= 0) {   // this group's rows of x_vqt; db_rows takes the frame from there
+            const GroupDev G = a.groups[g_only];
+            if (live)
+                for (int k = tl; k < G.n_rows; k += T) a.xv_split[(size_t)out_row * a.n_bins + G.first_bin + k] = xv[G.first_bin + k];
+            __syncthreads();
+            continue;
+        }
         if (a.out_cplx && live) {
             for (int k = tl; k < a.n_bins; k += T) a.out_cplx[(size_t)out_row * a.n_bins + k] = xv[k];
         }
         db_epilogue<T>(xv, red, a.n_bins, a.out_db + (size_t)out_row * a.n_bins, nullptr, tl, a.status, live);
         __syncthreads();
     }
+}
+
+// the frames of a group-split launch: x_vqt rows -> (optional complex output), frame-relative dB; T threads per row as in the walk
+template <int T>
+__global__ __launch_bounds__(T) void db_rows(const float2* __restrict__ xv_rows, int n_rows, int n_bins, float* __restrict__ out_db, float2* __restrict__ out_cplx,
+                                             unsigned* status) {
+    __shared__ float red[2 * (T / 64)];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (row >= n_rows) return;
+    const float2* xv = xv_rows + (size_t)row * n_bins;
+    if (out_cplx)
+        for (int k = tid; k < n_bins; k += T) out_cplx[(size_t)row * n_bins + k] = xv[k];
+    db_epilogue<T>(xv, red, n_bins, out_db + (size_t)row * n_bins, nullptr, tid, status, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -767,6 +797,7 @@ Vqt::~Vqt() {
         if (ws_flags_) (void)hipFree(ws_flags_);
         if (ws_stage_) (void)hipFree(ws_stage_);
         if (ws_stage_tab_) (void)hipFree(ws_stage_tab_);
+        if (ws_split_) (void)hipFree(ws_split_);
         for (void* b : multi_buf_)
             if (b) (void)hipFree(b);
         if (multi_stream_) (void)hipStreamDestroy(multi_stream_);
@@ -935,7 +966,20 @@ pvq_status Vqt::launch_fft_streams(const void* st_table, size_t n_st, const floa
     const int BLOCK = T == 1024 ? 1024 : 512;
     const int F = BLOCK / T;
     const size_t lds = (size_t)F * (sizeof(float2) * ((size_t)(n_tw + (n_tw >> 4)) + 1 + a.n_bins) + sizeof(float) * 2 * (T / 64));
-    const int grid = (int)std::min<size_t>((n_frames + F - 1) / F, 1u << 20);
+    int grid = (int)std::min<size_t>((n_frames + F - 1) / F, 1u << 20);
+    // few frames of one stream: a workgroup per window group (FftArgs::xv_split).  Measured against the walk (profiles/r04_fft_split.txt):
+    // 1 frame 47 -> 19 us at 48 kHz / 252 bins (77 -> 27 at 96 kHz / 360), ahead up to ~400 frames there (~200 at 96 kHz, ~750 at
+    // 22 050 Hz / 588 bins): up to ~1 500 workgroups, beyond which the chip is full either way and the walk's one pass over LDS wins
+    static const int split_env = dev_knob("PVQ_FFT_SPLIT", 1);   // (developer build: 0 = every workgroup walks its frames' groups)
+    static const int split_max_env = dev_knob("PVQ_FFT_SPLIT_MAX", 1500);
+    const bool split = !st_table && split_env && a.n_groups > 1 && (size_t)grid * (size_t)a.n_groups <= (size_t)split_max_env;
+    a.xv_split = nullptr;
+    if (split) {
+        pvq_status es = ensure_workspace(&ws_split_, &ws_split_cap_, n_frames * (size_t)a.n_bins * sizeof(float2));
+        if (es != PVQ_OK) return es;
+        a.xv_split = static_cast<float2*>(ws_split_);
+        grid *= a.n_groups;
+    }
     slot_begin(SLOT_FFT_FRAMES, stream);
     auto launch = [&](auto kern) -> pvq_status {
         PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -945,6 +989,13 @@ pvq_status Vqt::launch_fft_streams(const void* st_table, size_t n_st, const floa
     pvq_status lst = T == 128 ? launch(vqt_fft_frames<512, 16, 128>) : T == 256 ? launch(vqt_fft_frames<512, 16, 256>)
                      : T == 512 ? launch(vqt_fft_frames<512, 16, 512>) : launch(vqt_fft_frames<1024, 16, 1024>);
     if (lst != PVQ_OK) return lst;
+    if (split) {
+        const float2* rows = static_cast<const float2*>(ws_split_);
+        if (T == 128) hipLaunchKernelGGL(db_rows<128>, dim3((unsigned)n_frames), dim3(128), 0, stream, rows, (int)n_frames, a.n_bins, a.out_db, a.out_cplx, a.status);
+        else if (T == 256) hipLaunchKernelGGL(db_rows<256>, dim3((unsigned)n_frames), dim3(256), 0, stream, rows, (int)n_frames, a.n_bins, a.out_db, a.out_cplx, a.status);
+        else if (T == 512) hipLaunchKernelGGL(db_rows<512>, dim3((unsigned)n_frames), dim3(512), 0, stream, rows, (int)n_frames, a.n_bins, a.out_db, a.out_cplx, a.status);
+        else hipLaunchKernelGGL(db_rows<1024>, dim3((unsigned)n_frames), dim3(1024), 0, stream, rows, (int)n_frames, a.n_bins, a.out_db, a.out_cplx, a.status);
+    }
     slot_end(SLOT_FFT_FRAMES, stream);
     if (pk) {  // peak / note detection as its own launch (one wavefront per frame)
         slot_begin(SLOT_PEAKS, stream);
@@ -1037,8 +1088,8 @@ pvq_algo Vqt::resolve_algo(size_t hop, size_t n_frames) {
     return n_frames >= auto_block_min_frames(hop, r) ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;
 }
 
-// From how many frames on PVQ_ALGO_AUTO takes the block-DFT path (hop * r its block length).  A power-of-two hop: one tile row per
-// grid (the two paths cost the same 60-70 us there and the block path pulls away from ~500 frames on).  A general hop is different:
+// From how many frames on PVQ_ALGO_AUTO takes the block-DFT path (hop * r its block length).  A power-of-two hop: from 384 frames
+// (and at least one tile row per grid).  A general hop is different:
 // its tiles' K loops are hop * r / 2 deep, so a launch cannot end before ~180 us at 1 600 samples and ~300 us at 3 200 however few
 // frames it holds, while the FFT path — a workgroup per frame, 512 of them side by side — takes 53 us for up to ~420 frames and
 // 0.125 us per frame beyond (48 kHz / 252 bins; profiles/r04_small_batches.txt: 64 frames at hop 800 took 367 us on the block path
@@ -1058,7 +1109,9 @@ size_t Vqt::auto_block_min_frames(size_t hop, size_t r) const {
         for (uint32_t c : g.negative_filter_bank.col_idx) top = c > top ? c : top;
         cols += top + 1;
     }
-    if (divides) return 64 * r;
+    // (a power-of-two hop: both paths' launches are short; the block path's two kernels cost 58-67 us up to ~1 000 frames at 48 kHz /
+    // 252 bins, the FFT path — group-split for few frames, launch_fft_streams — 19 us for one frame, 42 for 256, 56 for 400)
+    if (divides) return std::max<size_t>(64 * r, 384);
     double t_fft = 3.0e-7 * fft_work;                                                     // us per frame, FFT path at scale
     if (plan_.params.n_fft > 0 && fft_work > 6.0e5) t_fft *= 1.35;                        // (a 32 768-sample window: 1 024 threads per frame, one workgroup per CU)
     const double floor_block = 58.0 + 0.075 * ((double)hop_eff - 256.0) + 18.0;           // us: shortest launch pair of the general-hop kernels

@@ -180,6 +180,7 @@ class Vqt {
     void* ws_flags_ = nullptr; size_t ws_flags_cap_ = 0;  // per-frame redo flags of the peak kernels
     void* ws_stage_ = nullptr; size_t ws_stage_cap_ = 0;  // many short streams staged one behind the other (batch_streams_device)
     void* ws_stage_tab_ = nullptr; size_t ws_stage_tab_cap_ = 0;
+    void* ws_split_ = nullptr; size_t ws_split_cap_ = 0;   // x_vqt rows of a group-split launch of the FFT path (few frames)
     // the multi-device driver's per-handle shard buffers (PCM, dB, mask, count, center, size) and stream, grow-only
     void* multi_buf_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t multi_cap_[6] = {0, 0, 0, 0, 0, 0};

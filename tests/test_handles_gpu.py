@@ -125,3 +125,24 @@ def test_handles_swapped_wholesale_do_not_leak_device_memory():
     for _ in range(29):
         last = one_round()
     assert first - last < (8 << 20), f"free device memory fell by {(first - last) / 2**20:.1f} MiB over 29 create / use / destroy rounds"
+
+
+@pytest.mark.parametrize("name,hop", [("bench_48k_252", 800), ("default_22k_588", 735), ("hires_96k_360", 1000), ("serial_22k_180", 441), ("bench_48k_288", 256)])
+def test_few_frames_on_the_fft_path_equal_the_same_frames_of_a_batch(name, hop):
+    """A call of a few frames (the streaming front end's single frame, a short clip) runs the FFT path group-split — a workgroup per
+    window group, the frames finished by db_rows — where a batch walks the groups inside one workgroup: same bits, dB rows and
+    complex coefficients, for 1 ... 40 frames cut out of a 300-frame batch at odd places"""
+    pp, _ = get_geom(name)
+    v = P.Vqt.new(pp, 0)
+    v.set_algo(P.ALGO_FFT)
+    nf, lead = 300, 1234
+    pcm = torch.from_numpy(white_noise(lead + hop * nf, 31 + hop)).cuda()
+    db = torch.empty((nf, v.n_bins), device="cuda"); cx = torch.empty((nf, v.n_bins, 2), device="cuda")
+    v.calculate_batch_db_device(pcm, hop, nf, db, n_lead=lead, d_out_cplx=cx)
+    for first, n in ((0, 1), (0, 3), (137, 1), (50, 17), (200, 40), (299, 1)):
+        sdb = torch.empty((n, v.n_bins), device="cuda"); scx = torch.empty((n, v.n_bins, 2), device="cuda")
+        # the same frames as a call of their own: everything before their first hop is lead
+        v.calculate_batch_db_device(pcm[: lead + hop * (first + n)], hop, n, sdb, n_lead=lead + hop * first, d_out_cplx=scx)
+        torch.cuda.synchronize()
+        assert torch.equal(sdb, db[first:first + n]) and torch.equal(scx, cx[first:first + n]), (first, n)
+    v.input_status()

@@ -142,8 +142,10 @@ def test_streams_feed_the_analysis_batch_on_the_device():
     d_db = torch.empty((n, nf, v.n_bins), device="cuda")
     v.batch_streams_device(pcms, hop, frames, d_db)
     d_ref = torch.empty_like(d_db)
+    v.set_algo(v.last_algo())    # (a single stream of 280 frames is below the 384 from which PVQ_ALGO_AUTO takes the block-DFT path)
     for s in range(n):
         v.calculate_batch_db_device(pcms[s], hop, nf, d_ref[s])
+    v.set_algo(P.ALGO_AUTO)
     torch.cuda.synchronize()
     assert torch.equal(d_db, d_ref)
     outs = []
