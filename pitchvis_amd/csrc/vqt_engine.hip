@@ -804,6 +804,8 @@ Vqt::~Vqt() {
         if (host_streams_ready_)
             for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(host_streams_[i]);
         for (hipEvent_t e : host_events_) (void)hipEventDestroy(e);
+        if (inst_stream_) (void)hipStreamDestroy(inst_stream_);
+        if (inst_pin_) (void)hipHostFree(inst_pin_);
         for (int s = 0; s < N_SLOTS; ++s)
             for (int k = 0; k < 2; ++k)
                 for (hipEvent_t e : ev_[s][k]) (void)hipEventDestroy(e);
@@ -1399,8 +1401,48 @@ pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* o
         set_last_error("input must be exactly n_fft samples");
         return PVQ_ERR_BAD_LENGTH;
     }
-    // one frame whose n_fft buffer is exactly x: hop = n_fft, no lead
-    return calculate_batch_db(x, 0, plan_.params.n_fft, 1, out_db);
+    if (!has_device()) {
+        set_last_error("handle was created without a device; there is no CPU fallback");
+        return PVQ_ERR_NO_DEVICE;
+    }
+    if (!x || !out_db) {
+        set_last_error("calculate_vqt_instant_in_db: null pointer");
+        return PVQ_ERR_INVALID_ARG;
+    }
+    // The reference's call shape — one frame, host slice in, host vector out (the viewer: once per rendered frame) — is latency, not
+    // throughput: the general host-buffer route (three streams, events, pageable copies of all n_fft samples, a flag read) took
+    // 77-92 us of which the GPU worked ~20.  Here: only the window union travels (the first n_fft - window_union samples are never
+    // read, SURVEY Appendix B: half of the buffer at 48 kHz, three quarters at the defaults), through page-locked staging on one
+    // stream with ONE wait; the non-finite check the kernels would flag is made on the host while the samples are staged; the
+    // frame runs the FFT path group-split (launch_fft_streams).  Same kernel, same samples: same bits as a batch of one.
+    PVQ_HIP(hipSetDevice(device_id_));
+    const size_t wu = plan_.window_union, nb = n_bins(), n_fft = plan_.params.n_fft;
+    if (!inst_stream_) PVQ_HIP(hipStreamCreateWithFlags(&inst_stream_, hipStreamNonBlocking));
+    if (!inst_pin_) PVQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&inst_pin_), (wu + nb) * sizeof(float), hipHostMallocDefault));
+    pvq_status st = ensure_workspace(&ws_pcm_, &ws_pcm_cap_, wu * sizeof(float));
+    if (st != PVQ_OK) return st;
+    st = ensure_workspace(&ws_out_, &ws_out_cap_, nb * sizeof(float));
+    if (st != PVQ_OK) return st;
+    const float* src = x + (n_fft - wu);
+    float bad = 0.0f;   // x - x is 0 for a finite x, NaN for NaN / Inf
+    for (size_t i = 0; i < wu; ++i) {
+        inst_pin_[i] = src[i];
+        bad += src[i] - src[i];
+    }
+    if (!(bad == 0.0f)) {
+        set_last_error("non-finite sample (NaN / Inf) in the input: the affected frames are unspecified (the reference's audio "
+                       "callback drops such chunks, audio_desktop.rs:102-105; peak_detection.rs:145 would panic)");
+        return PVQ_ERR_NONFINITE_INPUT;
+    }
+    PVQ_HIP(hipMemcpyAsync(ws_pcm_, inst_pin_, wu * sizeof(float), hipMemcpyHostToDevice, inst_stream_));
+    // frame 0 of a stream of `wu` samples with wu - 1 of them as history and a hop of 1: its n_fft buffer ends at the last sample
+    st = launch_fft_path(static_cast<const float*>(ws_pcm_), wu - 1, 1, 1, static_cast<float*>(ws_out_), nullptr, nullptr, inst_stream_);
+    if (st != PVQ_OK) return st;
+    last_algo_ = PVQ_ALGO_FFT;
+    PVQ_HIP(hipMemcpyAsync(inst_pin_ + wu, ws_out_, nb * sizeof(float), hipMemcpyDeviceToHost, inst_stream_));
+    PVQ_HIP(hipStreamSynchronize(inst_stream_));
+    std::copy(inst_pin_ + wu, inst_pin_ + wu + nb, out_db);
+    return PVQ_OK;
 }
 
 pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& a, hipStream_t stream) {

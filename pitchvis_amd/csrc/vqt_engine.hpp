@@ -165,6 +165,9 @@ class Vqt {
     bool host_streams_ready_ = false;
     hipStream_t host_streams_[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> host_events_;
+    // the single-frame call (calculate_vqt_instant_in_db): page-locked staging for the window union in and the dB values out, one stream
+    hipStream_t inst_stream_ = nullptr;
+    float* inst_pin_ = nullptr;   // [window_union + n_bins]
     bool twiddle_fp16_ = false;
     size_t workspace_limit_ = (size_t)1 << 30;   // bytes of X (+ Y) a sub-batch of the block-DFT path may take
     bool gemm_split_bf16_ = false;  // default PVQ_GEMM_F32; PVQ_GEMM_BF16X3 meets the same parity bars and is ~10 % faster end to end
