@@ -109,7 +109,10 @@ pvq_status pvq_vqt_filter_params(const pvq_vqt *v, float *freq, float *window_le
 /*
  * replaces Vqt::calculate_vqt_instant_in_db (vqt.rs:866-916): x = exactly n_fft host samples,
  * the last of which is "now"; out_db = n_bins host floats.  len != n_fft -> PVQ_ERR_BAD_LENGTH
- * (the reference panics).  Synchronous.
+ * (the reference panics).  Synchronous, and shaped for latency: only the window union of x (its last
+ * pvq_vqt_window_union samples: the kernel reads nothing before them) is staged, page-locked, on a stream of the handle's
+ * own; a non-finite sample among them returns PVQ_ERR_NONFINITE_INPUT before anything is launched (out_db untouched).
+ * Always the FFT path (one frame has nothing to share with a neighbour), whatever pvq_vqt_set_algo says.
  */
 pvq_status pvq_vqt_calculate_instant_db(pvq_vqt *v, const float *x, size_t len, float *out_db);
 
