@@ -25,6 +25,14 @@ extra key "config2" of the same line — at N = 1 too ("one GPU's share"), so th
 workload's efficiency can be computed from per-N values of ONE workload.  `--config 2` makes
 configs[2] the headline instead (developer use).
 
+The timed region and the device's clock.  An idle MI355X needs tens of milliseconds of load before its clock governor holds the
+sustained shader clock; W = 5 warm-up steps of this workload are 2.5 ms and K = 20 timed steps 10 ms, i.e. a window that lies
+wholly inside the ramp (measured on one box, same build: 131 M frames/s and a 305 us dominant kernel right after 5 warm-up steps,
+146-153 M and 262 us after 25 ms - 1 s of load, profiles/r04_bench_warmup.txt).  `value` is the SUSTAINED rate: the same step
+runs untimed for --settle-ms (default 300 ms) first, then the W warm-up steps, then EXACTLY K timed steps between barrier +
+synchronize on both sides.  The window a cold device gives — W warm-up steps from idle, then K timed steps, the first thing
+the process measures — is in the same line as "cold_start"; `--settle-ms 0` makes it the headline.
+
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -179,6 +187,8 @@ def main():
     ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the block-DFT GEMM / kernel product: fp32 MFMA (default, the library default) or the exact "
                          "3-way bf16 split on the bf16 matrix cores; the other one is measured too and reported as alt_gemm")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed load before the warm-up steps so that the timed region sees the device's sustained clock (0: none; the cold window is reported as cold_start either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-config", action="store_true", help="skip the second BASELINE configuration (the extra key config2 / config1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -248,22 +258,45 @@ def main():
             vqt.vqt_analyze_batch_device(d_pcm, HOP, shard.n_frames, d_db, d_mask, d_cnt, d_ctr, d_sz, max_peaks,
                                          n_lead=shard.n_lead)
 
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        vqt.set_profiling(2)   # HIP events around the dominant kernel's launches only, on the launch stream (every event record costs the stream ~3 us: the other kernels are timed in an untimed pass below)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        kernel_ms_main = vqt.last_kernel_ms()   # the dominant kernel, measured inside the timed region
+        def timed_region():
+            """W untimed warm-up steps, then EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks"""
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            vqt.set_profiling(2)   # HIP events around the dominant kernel's launches only, on the launch stream (every event record costs the stream ~3 us: the other kernels are timed in an untimed pass below)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            km = vqt.last_kernel_ms()
+            clk = vqt.last_sclk_mhz()   # shader clock inside the dominant kernel's K loop, sampled in the region's last launch
+            vqt.set_profiling(False)
+            if world > 1:
+                t = torch.tensor([dt_], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ = float(t.item())
+            return dt_, km, clk
+
+        # the window a cold device gives (the first thing this process measures on it) ...
+        dt_cold, km_cold, clk_cold = timed_region()
+        # ... then load until the clock governor has settled, and the window that counts
+        if args.settle_ms > 0:
+            t_end = time.perf_counter() + args.settle_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize()
+            dt, kernel_ms_main, clk_main = timed_region()
+        else:
+            dt, kernel_ms_main, clk_main = dt_cold, km_cold, clk_cold
+        # (kernel_ms_main: the dominant kernel, measured inside the timed region)
         # every kernel of a step, in an extra untimed pass of the same steps
         vqt.set_profiling(True)
         for _ in range(args.steps):
@@ -274,7 +307,8 @@ def main():
         kernel_ms.update(kernel_ms_main)
         r = dict(vqt=vqt, shard=shard, n_bins=n_bins, F=F, kernel_ms=kernel_ms, kernel_n=kernel_n, fpl=vqt.last_frames_per_launch(),
                  gemm_flop=vqt.last_gemm_flop(),     # flop the matrix instructions of one GEMM launch issue (tiles x 256 x 64 x depth x 2)
-                 sclk_mhz=vqt.last_sclk_mhz(),       # shader clock inside the GEMM kernel's K loop, sampled during the timed launches
+                 sclk_mhz=clk_main,                  # shader clock inside the GEMM kernel's K loop, sampled during the timed launches
+                 dt_cold=dt_cold, km_cold=km_cold, clk_cold=clk_cold,
                  algo=vqt.last_algo())
         vqt.set_profiling(False)
         if with_alt:
@@ -291,11 +325,7 @@ def main():
             r.update(other=other, dt_other=time.perf_counter() - t1, kernel_ms_other=vqt.last_kernel_ms())
             vqt.set_profiling(False)
             vqt.set_gemm_precision(P.GEMM_BF16X3 if args.gemm == "bf16x3" else P.GEMM_F32)
-        if world > 1:
-            t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        r["dt"] = dt
+        r["dt"] = dt   # (max over ranks: timed_region)
         # sanity: the output is real (not skipped work)
         assert torch.isfinite(d_db).all() and float(d_db.max()) > 0.0 and int(d_cnt.sum()) > 0
         return r
@@ -424,6 +454,22 @@ def main():
             "unit": "frames/s (this rank)",
             "ms_per_step": round(dt_other / args.steps * 1e3, 4),
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in kernel_ms_other.items()},
+        }
+        # the clock governor: what `value` waited for, and the window a cold device gives
+        g_cold = R["km_cold"].get("blockdft_gemm")
+        out["clock_settle"] = {
+            "ms": args.settle_ms,
+            "note": "untimed steps of the same workload before the W warm-up steps, so that the timed region sees the sustained shader clock "
+                    "(an idle MI355X ramps over tens of ms of load; W + K steps of this workload are 12.5 ms): bench.py's docstring, DESIGN.md 5"}
+        out["cold_start"] = {
+            "value": round(total_frames / R["dt_cold"], 1),
+            "unit": "frames/s",
+            "ms_per_step": round(R["dt_cold"] / args.steps * 1e3, 4),
+            "dominant_kernel_ms_per_launch": round(g_cold, 4) if g_cold else None,
+            "roofline_frac": round(gemm_flop / (g_cold * 1e-3) / 1e12 / peak, 5) if g_cold and gemm_flop > 0 and dom[0] == "blockdft_gemm" else None,
+            "sclk_mhz": round(R["clk_cold"], 1),
+            "note": "the first timed window of the process, measured the same way (W warm-up steps from an idle device, then K steps between "
+                    "barrier + synchronize, max over ranks); --settle-ms 0 makes it `value`",
         }
         if R2 is not None:
             # the other BASELINE bench configuration, same run, same K steps and barriers, its own timed region

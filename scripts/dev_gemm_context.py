@@ -1,6 +1,6 @@
 """What the dominant kernel's time depends on besides its own code (developer tool): the input signal (the matrix pipe's power
 draw follows the operands' toggle rate) and the kernels that run between two of its launches.
-usage: dev_gemm_context.py [iters]"""
+usage: [SETTLE_MS=300] dev_gemm_context.py [iters]"""
 import os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -28,6 +28,11 @@ def step():
     else: v.vqt_analyze_batch_device(d_pcm, hop, nf, d_db, d_mask, d_cnt, d_ctr, d_sz, 64)
 for _ in range(5): step()
 torch.cuda.synchronize()
+settle = float(os.environ.get("SETTLE_MS", "0")) * 1e-3   # load until the clock governor has settled (0: measure right after 5 warm-up steps)
+t_end = time.perf_counter() + settle
+while time.perf_counter() < t_end:
+    for _ in range(8): step()
+    torch.cuda.synchronize()
 v.set_profiling(2)
 t = time.perf_counter()
 for _ in range(n): step()
