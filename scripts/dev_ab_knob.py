@@ -14,6 +14,10 @@ d_pcm = (torch.rand(hop*nf, device="cuda") - 0.5) * 0.5
 d_db = torch.empty((nf, v.n_bins), device="cuda")
 for _ in range(3): v.calculate_batch_db_device(d_pcm, hop, nf, d_db)
 torch.cuda.synchronize()
+t_end = time.perf_counter() + float(os.environ.get("SETTLE_MS", "300")) * 1e-3   # until the device's clock governor has settled (profiles/r04_bench_warmup.txt)
+while time.perf_counter() < t_end:
+    for _ in range(8): v.calculate_batch_db_device(d_pcm, hop, nf, d_db)
+    torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(n): v.calculate_batch_db_device(d_pcm, hop, nf, d_db)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
