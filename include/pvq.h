@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVQ_ABI_VERSION 4   /* 4: + pvq_vqt_calculate_batch_db_streams, pvq_vqt_analyze_batch_streams (many streams per call), pvq_analysis_batch_preprocess_pcm, pvq_vqt_resolve_algo.  3: + pvq_vqt_set_workspace_limit, pvq_plan_shard, pvq_vqt_analyze_batch_multi, pvq_analysis_batch_*, profiling mode 2; per-call NaN flag semantics of the synchronous entry points */
+#define PVQ_ABI_VERSION 4   /* 4: + pvq_vqt_calculate_batch_db_streams, pvq_vqt_analyze_batch_streams (many streams per call).  3: + pvq_vqt_set_workspace_limit, pvq_plan_shard, pvq_vqt_analyze_batch_multi, pvq_analysis_batch_*, profiling mode 2; per-call NaN flag semantics of the synchronous entry points */
 
 /* replaces VqtParameters + VqtRange (vqt.rs:238-262, 278-331), flattened POD */
 typedef struct pvq_vqt_params {
