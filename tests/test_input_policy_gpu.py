@@ -85,3 +85,29 @@ def test_a_synchronous_call_answers_for_its_own_input_only():
     ref = v.calculate_batch_db(clean, hop, nf)                                    # clean input: PVQ_OK
     assert np.isfinite(ref).all()
     v.input_status()                                                               # and nothing is left behind
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_single_frame_call_checks_its_window_union_on_the_host(bad):
+    """pvq_vqt_calculate_instant_db (the reference's call shape) stages only the window union of its n_fft samples and looks at them
+    while it does: a non-finite sample among them is PVQ_ERR_NONFINITE_INPUT before anything is launched — no flag is left on the
+    device for a later call to trip over —, one before them (never read) is not an input"""
+    pp, op = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    x = white_noise(pp.n_fft, 9)
+    ref = v.calculate_vqt_instant_in_db(x)
+    wu = v.window_union
+    for at in (pp.n_fft - 1, pp.n_fft - wu, pp.n_fft - wu // 2):
+        y = x.copy(); y[at] = bad
+        with pytest.raises(P.PvqError) as e:
+            v.calculate_vqt_instant_in_db(y)
+        assert e.value.status == _lib.PVQ_ERR_NONFINITE_INPUT
+        v.input_status()                                     # nothing was raised on the device
+    y = x.copy(); y[pp.n_fft - wu - 1] = bad; y[0] = bad     # older than every window
+    assert np.array_equal(v.calculate_vqt_instant_in_db(y), ref)
+    assert np.array_equal(v.calculate_vqt_instant_in_db(x), ref)
+    # ... and the call is the same frame a batch of one gives
+    d = torch.from_numpy(x).cuda(); d_db = torch.empty((1, v.n_bins), device="cuda")
+    v.set_algo(P.ALGO_FFT)
+    v.calculate_batch_db_device(d, pp.n_fft, 1, d_db)
+    assert np.array_equal(d_db.cpu().numpy()[0], ref)
