@@ -43,13 +43,13 @@ constexpr int CB_C = GM_BN / 2;  // complex columns per combine workgroup
 constexpr int CB_MAX_NB = 256;  // hop blocks per window the combine tree supports (<= 64: 32-column tiles, else 16)
 // Frames per sub-batch: the X (+ Y) workspace is sized for one.  As many as the handle's workspace limit holds (default 1 GiB:
 // 131 072 frames at 48 kHz / 252 bins = 0.74 GB; wide geometries — 840 bins: 15 KB per frame — take fewer), a multiple of 64,
-// at most 131 072: one sub-batch per rank of BASELINE configs[2]; against two of 65 536 the step is 4 % shorter (one ramp and
+// at most 147 456 (BASELINE configs[2]'s 131 072 per rank is one sub-batch; against two of 65 536 the step is 4 % shorter: one ramp and
 // one tail per kernel instead of two); sub-batches small enough for the Infinity Cache were measured no faster (32 768: 9 % slower).
 static size_t chunk_frames(size_t limit_bytes, size_t bytes_per_frame) {
     const long knob = dev_knob("PVQ_CHUNK_FRAMES", 0);   // (developer build; read per call)
     if (knob >= 64) return (size_t)knob;
     size_t f = limit_bytes / std::max<size_t>(bytes_per_frame, 1) / 64 * 64;
-    return std::min<size_t>(std::max<size_t>(f, 64), 131072);
+    return std::min<size_t>(std::max<size_t>(f, 64), 147456);   // (131 072 + an eighth: 64 staged streams of 2 048 frames with their gaps are 135 168 frames — one launch, not one and a 4 000-frame tail)
 }
 
 struct BlockGroup {

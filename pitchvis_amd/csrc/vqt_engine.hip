@@ -1223,8 +1223,8 @@ pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_
             }
             shorts.clear();
         }
-        // staged buffers of at most ~128 K frames and 512 MiB each, filled and analysed one after the other on `stream`
-        const size_t vcap = std::max<size_t>(A * 4, std::min<size_t>((size_t)131072, ((size_t)512 << 20) / (hop * sizeof(float))) / A * A);
+        // staged buffers of at most 144 K frames (one sub-batch of the block-DFT path) and 512 MiB each, filled and analysed one after the other on `stream`
+        const size_t vcap = std::max<size_t>(A * 4, std::min<size_t>((size_t)147456, ((size_t)512 << 20) / (hop * sizeof(float))) / A * A);
         size_t at = 0;
         while (at < shorts.size()) {
             std::vector<Slot> slots;

@@ -16,6 +16,10 @@ def bench(fn, reps=20, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    t_end = time.perf_counter() + 0.3   # until the device's clock governor has settled (profiles/r04_bench_warmup.txt)
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
