@@ -186,7 +186,7 @@ pvq_status pvq_vqt_set_gemm_precision(pvq_vqt *v, pvq_gemm_precision p);
 pvq_status pvq_vqt_set_twiddle_fp16(pvq_vqt *v, int enable);
 /* Upper bound, in bytes, of the block-DFT path's intermediate spectrum workspace of this handle (grow-only device memory,
  * ~5.6 KB per frame of a sub-batch at 48 kHz / 252 bins, more with more spectrum columns).  A batch longer than the workspace
- * holds is processed in sub-batches of a multiple of 64 frames, at most 131 072.  Default (and bytes == 0): 1 GiB.  The
+ * holds is processed in sub-batches of a multiple of 64 frames, at most 147 456.  Default (and bytes == 0): 1 GiB.  The
  * reference's trainer keeps one Vqt per worker thread (pitchvis_train/src/train.rs:146-155): size this per handle. */
 pvq_status pvq_vqt_set_workspace_limit(pvq_vqt *v, uint64_t bytes);
 /* complex spectrum columns per hop block the block-DFT GEMM computes (padded), 0 before its first use */
