@@ -577,6 +577,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     uint32_t* n_bass = counts + PK_FPG;
     float* thrH = reinterpret_cast<float*>(n_bass + 1);                                // [npad] per-bin height / prominence thresholds of the candidate test
     float* thrP = thrH + npad;
+    // the wave's first frames are asked for before the workgroup fills its threshold table and meets at the barrier: the loads fly meanwhile
+    float pre[PK_FPW][NK <= 12 ? NK : 1];
+    if (NK <= 12) {
+#pragma unroll
+        for (int g = 0; g < PK_FPW; ++g) {
+            const int frame = blockIdx.x * PK_FPG + wv * PK_FPW + g;
+            const float* src = db + (size_t)(frame < n_frames ? frame : 0) * n;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = (k << 6) + lane;
+                pre[g][k] = ((k << 6) < n) ? src[i < n ? i : n - 1] : 0.0f;
+            }
+        }
+    }
     if (NK <= 12) {   // (beyond 768 bins peaks_lean_scan computes them on the fly)
         peaks_lean_thresholds(thrH, thrP, a, tid, PK_WAVES * 64);
         __syncthreads();
@@ -604,11 +618,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
                 float* x = rows + fi * row + PK_PAD;
                 const float* src = db + (size_t)frame * n;
                 if (NK <= 12) {
+                    const bool first = base == (int)(blockIdx.x * PK_FPG);   // (uniform) the prefetched pass
 #pragma unroll
                     for (int k = 0; k < NK; ++k) {   // the frame into its row (the tail of its last 64 stays +INF)
                         if ((k << 6) >= n) break;
                         const int i = (k << 6) + lane;
-                        const float t = src[i < n ? i : n - 1];
+                        const float t = first ? pre[g][k] : src[i < n ? i : n - 1];
                         x[i] = i < n ? t : __builtin_huge_valf();
                     }
                 } else {
