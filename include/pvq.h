@@ -142,12 +142,18 @@ pvq_status pvq_vqt_calculate_batch_db_device(pvq_vqt *v, const float *d_pcm, siz
  * callback drops such chunks, pitchvis_audio/src/audio_desktop.rs:102-105), and the NaNs they would cause make its peak
  * stage panic (peak_detection.rs:145 `partial_cmp().unwrap()`).  Here a non-finite sample inside one of a frame's windows
  * raises a sticky flag on the device while the frame's dB values are computed; the frames it touches are unspecified.
- * The synchronous host-buffer entry points (pvq_vqt_calculate_instant_db, pvq_vqt_calculate_batch_db, pvq_train_frames_db)
- * check the flag themselves and return PVQ_ERR_NONFINITE_INPUT.  For the asynchronous device-pointer entry points call
- * this: it waits for `stream`, returns PVQ_ERR_NONFINITE_INPUT if the flag is up (PVQ_OK otherwise) and clears it (read and
- * clear are one stream-ordered step on `stream`: poll on the stream the work was queued on).  The flag is per handle: a
- * synchronous entry point reports its own input only — it clears, unreported, whatever an earlier asynchronous call of the
- * same handle raised and nobody polled.
+ * The synchronous host-buffer batch entry points (pvq_vqt_calculate_batch_db, pvq_train_frames_db) check the flag themselves
+ * and return PVQ_ERR_NONFINITE_INPUT; such a call reports its own input only — it clears, unreported, whatever an earlier
+ * asynchronous call of the same handle raised and nobody polled.  pvq_vqt_calculate_instant_db does not use the flag at all: it
+ * checks its window union on the host while staging it, launches nothing on a non-finite sample, and neither reads nor clears what
+ * an earlier asynchronous call left behind.  For the asynchronous device-pointer entry points call this: it waits for `stream`,
+ * returns PVQ_ERR_NONFINITE_INPUT if the flag is up (PVQ_OK otherwise) and clears it (read and clear are one stream-ordered step on
+ * `stream`: poll on the stream the work was queued on).  The flag is per handle.
+ *
+ * Ordering of one handle's calls.  The handle owns its workspaces, so its device calls are ordered: a call on another stream than
+ * the handle's previous call — pvq_vqt_calculate_instant_db and pvq_stream_frame_db run on streams of their own — first makes its
+ * stream wait, on the device, for everything the previous call queued (the host does not block; calls that stay on one stream pay
+ * nothing).  The handle itself is still not thread-safe: one handle per thread, as one `&mut Vqt` in the reference.
  */
 pvq_status pvq_vqt_input_status(pvq_vqt *v, void *stream);
 

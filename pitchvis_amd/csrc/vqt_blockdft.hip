@@ -1989,13 +1989,20 @@ float Vqt::last_sclk_mhz() {
 uint32_t Vqt::blockdft_columns() const { return (dev_ && dev_->block) ? (uint32_t)(dev_->block->n_tiles * CB_C) : 0u; }
 
 // whether the block-DFT path can take several streams in one launch (the fused GEMM + tree kernels; the unfused fallback stages —
-// more than 8 window groups — run one stream per call)
-bool Vqt::blockdft_takes_streams(size_t hop) {
-    if (!blockdft_applicable(hop) || prepare_blockdft(hop) != PVQ_OK) return false;
-    const BlockDftTables* t = dev_->block;
-    if (t->general) return true;
+// more than 8 window groups — run one stream per call).  A pure predicate on the plan: it builds no tables and evicts none (a query
+// such as pvq_vqt_resolve_algo must not move the handle's tables of the hop in use, let alone allocate on whatever device is current).
+bool Vqt::blockdft_takes_streams(size_t hop) const {
+    if (!blockdft_applicable(hop)) return false;
+    const auto& groups = plan_.kernel.window_groups;
+    bool divides = (hop & (hop - 1)) == 0;
+    size_t nb_max = 0;
+    for (const WindowGroup& g : groups) {
+        divides = divides && g.window_size() % hop == 0;
+        nb_max = std::max(nb_max, g.window_size() / hop);
+    }
+    if (!divides) return true;   // a general hop: blockdft_gemm_gen (blockdft_applicable has checked its conditions)
     const bool use_bf = gemm_split_bf16_ && hop % FB_BK == 0;
-    return !dev_knob("PVQ_NO_FUSE", 0) && t->nb_max <= CB_MAX_NB && t->n_groups <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
+    return !dev_knob("PVQ_NO_FUSE", 0) && nb_max <= (size_t)CB_MAX_NB && groups.size() <= 8 && hop % (use_bf ? FB_BK : 64) == 0;
 }
 
 bool Vqt::blockdft_applicable(size_t hop) const {
@@ -2027,6 +2034,7 @@ static bool up(T** dst, const std::vector<T>& src) {
 
 pvq_status Vqt::prepare_blockdft(size_t hop) {
     if (dev_->block && dev_->block->hop == hop) return PVQ_OK;
+    PVQ_HIP(hipSetDevice(device_id_));   // the tables live on the handle's device, whatever device the calling thread has current
     if (dev_->block) {
         free_blockdft_tables(dev_->block);
         dev_->block = nullptr;

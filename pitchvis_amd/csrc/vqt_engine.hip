@@ -820,6 +820,7 @@ Vqt::~Vqt() {
             for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(host_streams_[i]);
         for (hipEvent_t e : host_events_) (void)hipEventDestroy(e);
         if (inst_stream_) (void)hipStreamDestroy(inst_stream_);
+        if (order_ev_) (void)hipEventDestroy(order_ev_);
         if (inst_pin_) (void)hipHostFree(inst_pin_);
         for (int s = 0; s < N_SLOTS; ++s)
             for (int k = 0; k < 2; ++k)
@@ -1052,6 +1053,23 @@ pvq_status Vqt::vqt_analyze_batch_device(const float* d_pcm, size_t n_lead, size
     return run_batch(d_pcm, n_lead, hop, n_frames, d_out_db, nullptr, &pk, stream);
 }
 
+pvq_status Vqt::order_on(hipStream_t s) {
+    if (order_valid_ && order_stream_ != s) {
+        if (!order_ev_) PVQ_HIP(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
+        // a marker behind everything the previous call queued; should its stream be gone (destroyed by the caller: an invalid
+        // handle), a stream that no longer exists has nothing in flight that a device-wide wait would not cover
+        if (hipEventRecord(order_ev_, order_stream_) == hipSuccess) {
+            PVQ_HIP(hipStreamWaitEvent(s, order_ev_, 0));
+        } else {
+            (void)hipGetLastError();
+            PVQ_HIP(hipDeviceSynchronize());
+        }
+    }
+    order_stream_ = s;
+    order_valid_ = true;
+    return PVQ_OK;
+}
+
 pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, float* d_out_db,
                           float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream) {
     if (!has_device()) {
@@ -1064,6 +1082,10 @@ pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t 
         return PVQ_ERR_INVALID_ARG;
     }
     PVQ_HIP(hipSetDevice(device_id_));
+    {
+        pvq_status os = order_on(stream);
+        if (os != PVQ_OK) return os;
+    }
     // The block-DFT path takes the hop itself (r = 1), or — a hop it cannot take but whose r-fold it can, 800 -> 1 600 — r interleaved
     // block grids of hop r * hop: grid i holds the frames i, i + r, ... (each hop' block is then transformed once per grid)
     const size_t r = blockdft_hop_factor(hop);
@@ -1097,7 +1119,7 @@ pvq_status Vqt::run_batch(const float* d_pcm, size_t n_lead, size_t hop, size_t 
 
 // which path run_batch takes for a batch of this shape (the multi-device driver decides once for the WHOLE stream, so that a shard of a
 // few frames runs the path the unsharded stream runs: the two paths agree to the parity bars, not bit for bit)
-pvq_algo Vqt::resolve_algo(size_t hop, size_t n_frames) {
+pvq_algo Vqt::resolve_algo(size_t hop, size_t n_frames) const {
     if (algo_ == PVQ_ALGO_FFT) return PVQ_ALGO_FFT;
     const size_t r = blockdft_hop_factor(hop);
     if (r == 0 || (r > 1 && !blockdft_takes_streams(hop * r))) return algo_ == PVQ_ALGO_BLOCKDFT ? PVQ_ALGO_BLOCKDFT : PVQ_ALGO_FFT;   // (forced: run_batch reports the error)
@@ -1187,6 +1209,10 @@ pvq_status Vqt::batch_streams_device(const float* const* d_pcm, const size_t* n_
         return PVQ_ERR_UNSUPPORTED;
     }
     PVQ_HIP(hipSetDevice(device_id_));
+    {
+        pvq_status os = order_on(stream);
+        if (os != PVQ_OK) return os;
+    }
     const size_t nb = n_bins();
     // rows a stream does not fill are zero frames: nothing reads uninitialised memory, their peak outputs say "no peaks"
     if (ragged) PVQ_HIP(hipMemsetAsync(d_out_db, 0, rows_total * nb * sizeof(float), stream));
@@ -1378,6 +1404,14 @@ pvq_status Vqt::calculate_batch_db(const float* pcm, size_t n_lead, size_t hop, 
     float* d_pcm = static_cast<float*>(ws_pcm_);
     float* d_out = static_cast<float*>(ws_out_);
     size_t sample_done = 0;
+    // the path is decided ONCE for the whole call and pinned for its parts (as analyze_batch_multi does for its shards): left to itself
+    // PVQ_ALGO_AUTO would send a tail part below its threshold to the FFT path, whose values agree with the block-DFT path's to the
+    // parity bars, not bit for bit — one synchronous call would mix the two
+    struct AlgoPin {
+        Vqt* v; pvq_algo saved;
+        AlgoPin(Vqt* vv, pvq_algo a) : v(vv), saved(vv->algo()) { v->set_algo(a); }
+        ~AlgoPin() { v->set_algo(saved); }
+    } pin(this, resolve_algo(hop, n_frames));
     for (size_t p = 0; p < n_parts; ++p) {
         const size_t fbeg = p * PART, nf = std::min(PART, n_frames - fbeg);
         const size_t sample_end = n_lead + (fbeg + nf) * hop;
@@ -1434,6 +1468,10 @@ pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* o
     const size_t wu = plan_.window_union, nb = n_bins(), n_fft = plan_.params.n_fft;
     if (!inst_stream_) PVQ_HIP(hipStreamCreateWithFlags(&inst_stream_, hipStreamNonBlocking));
     if (!inst_pin_) PVQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&inst_pin_), (wu + nb) * sizeof(float), hipHostMallocDefault));
+    {   // (an asynchronous batch still queued on the caller's stream owns ws_pcm_ / ws_out_ / the group-split rows until it is done)
+        pvq_status os = order_on(inst_stream_);
+        if (os != PVQ_OK) return os;
+    }
     pvq_status st = ensure_workspace(&ws_pcm_, &ws_pcm_cap_, wu * sizeof(float));
     if (st != PVQ_OK) return st;
     st = ensure_workspace(&ws_out_, &ws_out_cap_, nb * sizeof(float));
@@ -1522,6 +1560,10 @@ pvq_status Vqt::analyze_batch_device(const float* d_db, size_t n_frames, const A
         return PVQ_ERR_UNSUPPORTED;
     }
     PVQ_HIP(hipSetDevice(device_id_));
+    {
+        pvq_status os = order_on(stream);
+        if (os != PVQ_OK) return os;
+    }
     slot_begin(SLOT_PEAKS, stream);
     pvq_status ps = launch_peaks_kernel(d_db, n_frames, a, stream);
     slot_end(SLOT_PEAKS, stream);

@@ -85,7 +85,7 @@ class Vqt {
 
     void set_algo(pvq_algo a) { algo_ = a; }
     pvq_algo algo() const { return algo_; }
-    pvq_algo resolve_algo(size_t hop, size_t n_frames);   // the path a batch of this shape takes under the current setting
+    pvq_algo resolve_algo(size_t hop, size_t n_frames) const;   // the path a batch of this shape takes under the current setting
     // block-DFT GEMM arithmetic: exact fp32 MFMA, or the split-bf16 (3 x bf16, fp32 accumulate) form
     void set_gemm_split_bf16(bool on) { gemm_split_bf16_ = on; }
     void set_workspace_limit(size_t bytes) { workspace_limit_ = bytes ? bytes : ((size_t)1 << 30); }   // block-DFT spectrum workspace
@@ -127,7 +127,7 @@ class Vqt {
     pvq_status launch_fft_streams(const void* st_table, size_t n_st, const float* d_pcm, size_t n_lead, size_t hop, size_t n_frames, size_t rows_total,
                                   float* d_out_db, float* d_out_cplx, const PeakParamsDev* pk, hipStream_t stream);   // st_table: FftStream[n_st] (vqt_engine.hip) or null
     bool blockdft_applicable(size_t hop) const;
-    bool blockdft_takes_streams(size_t hop);
+    bool blockdft_takes_streams(size_t hop) const;
     // One run of frames for the block-DFT path: frame f' (of n_frames) ends at sample first_end + f' * hop of a buffer of n_samples
     // valid samples (zeros before it and after it) and goes to output row out_row0 + f' * row_step.  A stream of a many-streams call is
     // one run (first_end = n_lead + hop, row_step 1); a hop the path cannot take itself but whose r-fold it can (800 -> 1 600) is r
@@ -153,6 +153,11 @@ class Vqt {
     pvq_status ensure_workspace(void** ptr, size_t* cap, size_t bytes);
     pvq_status launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& p, hipStream_t s);
     void slot_begin(int slot, hipStream_t s);
+    // One handle's calls are ORDERED: the workspaces (X, the group-split rows, staging buffers, tile-list slots, the peak kernels' redo
+    // flags) belong to the handle, so a call on another stream than the previous call's — the single-frame route's own stream after an
+    // asynchronous batch on the caller's, a pvq_stream's stream, a second user stream — first makes its stream wait (on the device, the
+    // host does not block) for everything the previous call queued.  Calls that stay on one stream pay nothing.
+    pvq_status order_on(hipStream_t s);
     void slot_end(int slot, hipStream_t s);
 
     HostPlan plan_;
@@ -167,6 +172,9 @@ class Vqt {
     std::vector<hipEvent_t> host_events_;
     // the single-frame call (calculate_vqt_instant_in_db): page-locked staging for the window union in and the dB values out, one stream
     hipStream_t inst_stream_ = nullptr;
+    hipStream_t order_stream_ = nullptr;   // the stream of the handle's previous device call (order_on)
+    bool order_valid_ = false;
+    hipEvent_t order_ev_ = nullptr;
     float* inst_pin_ = nullptr;   // [window_union + n_bins]
     bool twiddle_fp16_ = false;
     size_t workspace_limit_ = (size_t)1 << 30;   // bytes of X (+ Y) a sub-batch of the block-DFT path may take

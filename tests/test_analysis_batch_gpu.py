@@ -31,7 +31,7 @@ from synth import piano_roll
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-OUT = "analysis_batch_r04.txt"
+OUT = "analysis_batch_r05.txt"
 FIELDS = ("x_vqt_smoothed", "x_vqt_peakfiltered", "x_vqt_afterglow", "calmness", "pitch_accuracy", "pitch_deviation")
 # GPU batch vs oracle on IDENTICAL dB frames.  The recurrence state (EMAs of dB values 0..60 and of calmness 0..1) may differ by
 # an ulp where an EMA weight rounded the other way; the continuous peaks come out of an ill-conditioned f32 parabola in
@@ -72,9 +72,9 @@ def _set_mode(obj, mode, ns=False):
         obj.update_vqt_smoothing_duration(120_000_000 if ns else 0.120)
 
 
-def _oracle_reference(rng_, x, times_ns, mode):
+def _oracle_reference(rng_, x, times_ns, mode, okw=None):
     """oracle/analysis_state.py over one stream: every pub field per frame (times_ns: one duration, or one per frame)"""
-    st = OracleAnalysisStateVec(rng_.min_freq, rng_.octaves, rng_.buckets_per_octave)
+    st = OracleAnalysisStateVec(rng_.min_freq, rng_.octaves, rng_.buckets_per_octave, **(okw or {}))
     _set_mode(st, mode, ns=True)
     nf, nb = x.shape
     out = {k: np.empty((nf, nb), np.float32) for k in FIELDS}
@@ -91,9 +91,9 @@ def _oracle_reference(rng_, x, times_ns, mode):
     return out
 
 
-def _host_reference(rng_, x, dt, mode):
+def _host_reference(rng_, x, dt, mode, fp=None):
     """the product's host AnalysisState over one stream (second reference)"""
-    st = P.AnalysisState.new(rng_)
+    st = P.AnalysisState(rng_, fp) if fp is not None else P.AnalysisState.new(rng_)
     _set_mode(st, mode)
     nf, nb = x.shape
     out = {k: np.empty((nf, nb), np.float32) for k in FIELDS}
@@ -226,6 +226,65 @@ def test_gpu_streams_follow_the_oracle(bpo, octaves, n_streams, n_frames, mode):
     for k in ("x_vqt_smoothed", "calmness", "x_vqt_afterglow"):   # the recurrence's own state: all but a handful of values equal bit for bit
         assert tally.same[k] >= 0.999 * tally.total[k], (k, tally.same[k], tally.total[k])
     assert tally.same["scene"] >= 0.99 * tally.total["scene"]   # (a power-weighted mean: one powf rounded the other way moves it by an ulp)
+
+
+# every field of AnalysisParameters (analysis.rs:36-65) moved off its default (analysis.rs:72-98): as the product's parameter object and as
+# the oracle's keywords
+NONDEFAULT = dict(
+    full=dict(peak_config=(8.0, 3.0), bassline_peak_config=(4.0, 2.5), highest_bassnote=20, vqt_smoothing_duration_base=0.040,
+              vqt_smoothing_calmness_min=0.5, vqt_smoothing_calmness_max=3.0, note_calmness_smoothing_duration=2.0,
+              scene_calmness_smoothing_duration=0.5, tuning_inaccuracy_smoothing_duration=3.0, harmonic_threshold=0.2),
+    oracle=dict(peak=(8.0, 3.0), bass=(4.0, 2.5), highest_bassnote=20, base_ns=40_000_000, cmin=0.5, cmax=3.0, note_ns=2_000_000_000,
+                scene_ns=500_000_000, tuning_ns=3_000_000_000, harmonic_threshold=0.2))
+
+
+def _nondefault_params():
+    f = NONDEFAULT["full"]
+    return P.FullAnalysisParameters(peak_config=P.PeakDetectionParameters(*f["peak_config"]), bassline_peak_config=P.PeakDetectionParameters(*f["bassline_peak_config"]),
+                                    **{k: v for k, v in f.items() if k not in ("peak_config", "bassline_peak_config")})
+
+
+@pytest.mark.parametrize("bpo,octaves,n_streams,n_frames,per_frame_dt", [(36, 7, 12, 400, False), (84, 7, 6, 260, False), (36, 7, 6, 300, True)])
+def test_gpu_streams_non_default_parameters(bpo, octaves, n_streams, n_frames, per_frame_dt):
+    """The GPU batch with EVERY field of AnalysisParameters off its default (analysis.rs:36-98: peak 8.0 / 3.0, bass 4.0 / 2.5 with the split
+    at bin 20, a 40 ms base horizon stretched by calmness 0.5 ... 3.0, note / scene / tuning horizons 2 s / 0.5 s / 3 s, harmonic threshold
+    0.2) against the oracle with the same values: the host-built EMA-weight table is sized from base * 1.5 * calmness_max + 3 entries, the
+    bass / general split and both find_peaks configurations move, the promotion test changes.  The third case gives every frame its own
+    duration (one table row per distinct frame time)."""
+    rng_ = P.VqtRange(55.0, octaves, bpo)
+    nb = octaves * bpo
+    max_peaks = 64
+    dt = 0.016
+    rng = np.random.default_rng(99 + bpo)
+    times = (np.round(rng.uniform(0.004, 0.034, n_frames) * 1e6) * 1e-6) if per_frame_dt else None
+    times_ns = np.round(times * 1e9).astype(np.int64) if per_frame_dt else int(round(dt * 1e9))
+    x = _frames(n_streams, n_frames, nb, 4321 + bpo + n_streams)
+    fp = _nondefault_params()
+    b = P.AnalysisBatch(rng_, n_streams, params=fp)
+    outs = _alloc_outputs(n_streams, n_frames, nb, max_peaks)
+    b.preprocess_device(torch.from_numpy(x).cuda(), n_frames, dt, outs, max_peaks=max_peaks, frame_times=times)
+    torch.cuda.synchronize()
+    g = _to_host(outs, nb)
+    tally, host_tally = _Tally(), _Tally()
+    default_masks_differ = 0
+    for s in range(n_streams):
+        w = _oracle_reference(rng_, x[s], times_ns, "default", NONDEFAULT["oracle"])
+        _compare_stream(tally, g, s, w, n_frames, max_peaks, TOL, "oracle, non-default parameters")
+        if s < 2:
+            default_masks_differ += int((_oracle_reference(rng_, x[s], times_ns, "default")["mask"] != w["mask"]).sum())
+            if not per_frame_dt:
+                _compare_stream(host_tally, g, s, _host_reference(rng_, x[s], dt, "default", fp), n_frames, max_peaks, TOL, "host, non-default parameters")
+    assert default_masks_differ > 0   # (the moved parameters do change the answer: this is not the default case again)
+    lines = [f"analysis batch vs ORACLE with non-default AnalysisParameters, {bpo} bpo x {octaves} oct, {n_streams} streams x {n_frames} frames"
+             f"{', a duration per frame' if per_frame_dt else ''}: peak sets equal in all {n_streams * n_frames} frames ({default_masks_differ} mask bits differ from the default parameters' on 2 streams)"]
+    lines += tally.lines()
+    if host_tally.total:
+        lines.append("  against the product's host AnalysisState (2 streams):")
+        lines += host_tally.lines()
+    for ln in lines:
+        report(OUT, ln)
+    for k in ("x_vqt_smoothed", "calmness", "x_vqt_afterglow"):
+        assert tally.same[k] >= 0.999 * tally.total[k], (k, tally.same[k], tally.total[k])
 
 
 def _margin(frame, b, rng_, ap):

@@ -146,3 +146,70 @@ def test_few_frames_on_the_fft_path_equal_the_same_frames_of_a_batch(name, hop):
         torch.cuda.synchronize()
         assert torch.equal(sdb, db[first:first + n]) and torch.equal(scx, cx[first:first + n]), (first, n)
     v.input_status()
+
+
+def test_resolve_algo_is_a_pure_query():
+    """pvq_vqt_resolve_algo answers from the plan alone: before the first batch it builds no block-DFT tables (blockdft_columns stays 0 — it used to
+    build those of hop * r on whatever device was current), and between two batches it leaves the tables of the hop in use where they are."""
+    pp, _ = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    assert v.blockdft_columns() == 0
+    assert v.resolve_algo(800, 100000) == P.ALGO_BLOCKDFT and v.resolve_algo(800, 64) == P.ALGO_FFT
+    assert v.resolve_algo(320, 100000) == P.ALGO_BLOCKDFT and v.resolve_algo(735, 100000) == P.ALGO_FFT
+    assert v.blockdft_columns() == 0
+    nf = 2000
+    pcm = torch.from_numpy(white_noise(256 * nf, 5)).cuda()
+    a, b = torch.empty((nf, v.n_bins), device="cuda"), torch.empty((nf, v.n_bins), device="cuda")
+    v.calculate_batch_db_device(pcm, 256, nf, a)
+    cols = v.blockdft_columns()
+    assert cols > 0
+    assert v.resolve_algo(800, 100000) == P.ALGO_BLOCKDFT
+    assert v.blockdft_columns() == cols
+    v.calculate_batch_db_device(pcm, 256, nf, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_single_frame_call_behind_an_asynchronous_batch_on_another_stream():
+    """One handle's calls are ordered (pvq.h): calculate_vqt_instant_in_db runs on a stream of the handle's own and shares the handle's
+    workspaces with a batch that may still be queued on the caller's stream.  A few-frame batch on the group-split FFT route (it writes the same
+    scratch rows the single-frame route does) is queued behind a long block-DFT batch on a user stream and, without waiting, the single-frame
+    call follows; both must give what they give alone."""
+    pp, _ = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    n_fft = pp.n_fft
+    x = white_noise(n_fft, 901)
+    alone = v.calculate_vqt_instant_in_db(x)
+    nf_long, nf_few = 60000, 24
+    pcm_long = torch.from_numpy(white_noise(256 * nf_long, 11)).cuda()
+    pcm_few = torch.from_numpy(white_noise(256 * nf_few + 300, 12)).cuda()
+    ref_few = torch.empty((nf_few, v.n_bins), device="cuda")
+    v.calculate_batch_db_device(pcm_few, 256, nf_few, ref_few, n_lead=300)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    for _ in range(5):
+        out_long = torch.empty((nf_long, v.n_bins), device="cuda")
+        out_few = torch.full((nf_few, v.n_bins), -1.0, device="cuda")
+        torch.cuda.synchronize()
+        v.calculate_batch_db_device(pcm_long, 256, nf_long, out_long, stream=st)
+        v.calculate_batch_db_device(pcm_few, 256, nf_few, out_few, n_lead=300, stream=st)
+        got = v.calculate_vqt_instant_in_db(x)          # returns while `st` may still be busy
+        assert np.array_equal(got.view(np.uint32), alone.view(np.uint32))
+        st.synchronize()
+        assert torch.equal(out_few.view(torch.int32), ref_few.view(torch.int32))
+
+
+@pytest.mark.parametrize("hop", [256, 1600])
+def test_host_batch_in_parts_takes_one_path(hop):
+    """calculate_batch_db pipelines a large host batch in 16 384-frame parts; the path is resolved once for the whole call, so a tail part below
+    PVQ_ALGO_AUTO's threshold does not switch to the FFT path: the host call equals the device call of the whole batch bit for bit."""
+    pp, _ = get_geom("bench_48k_252")
+    v = P.Vqt.new(pp, 0)
+    nf = 2 * 16384 + 500
+    pcm = white_noise(hop * nf + 77, 31 + hop)
+    host = v.calculate_batch_db(pcm, hop, nf, n_lead=77)
+    assert v.last_algo() == P.ALGO_BLOCKDFT
+    d = torch.empty((nf, v.n_bins), device="cuda")
+    v.calculate_batch_db_device(torch.from_numpy(pcm).cuda(), hop, nf, d, n_lead=77)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.view(np.uint32), d.cpu().numpy().view(np.uint32))

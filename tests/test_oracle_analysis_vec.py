@@ -34,10 +34,14 @@ def same_bits(a, b):
 
 
 @pytest.mark.parametrize("bpo,octaves,mode,jitter", [(36, 7, "default", False), (36, 7, "default", True), (84, 3, "default", False),
-                                                      (36, 5, "none", False), (36, 7, "retuned", True), (36, 4, "zero_base", False)])
+                                                      (36, 5, "none", False), (36, 7, "retuned", True), (36, 4, "zero_base", False),
+                                                      (36, 7, "nondefault", True), (84, 3, "nondefault", False)])
 def test_array_form_equals_scalar_form_bit_for_bit(bpo, octaves, mode, jitter):
     n = bpo * octaves
     kw = dict(base_ns=0) if mode == "zero_base" else {}
+    if mode == "nondefault":   # every AnalysisParameters field off its default (the GPU batch's non-default test leans on the array form here too)
+        kw = dict(peak=(8.0, 3.0), bass=(4.0, 2.5), highest_bassnote=20, base_ns=40_000_000, cmin=0.5, cmax=3.0, note_ns=2_000_000_000,
+                  scene_ns=500_000_000, tuning_ns=3_000_000_000, harmonic_threshold=0.2)
     a, b = OracleAnalysisState(55.0, octaves, bpo, **kw), OracleAnalysisStateVec(55.0, octaves, bpo, **kw)
     if mode == "none":
         a.update_vqt_smoothing_duration(None); b.update_vqt_smoothing_duration(None)
