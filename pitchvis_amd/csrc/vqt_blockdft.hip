@@ -136,7 +136,8 @@ struct BlockDftTables {
         bool multi = false;
         double eff_tiles = 0.0;                       // MFMA work of the list in whole 32-column tiles
         double eff_flop = 0.0;                        // ... in flop (general hops: the depth differs by tile kind and group)
-    } tile_lists[4];   // four slots: a batch's first, middle and last sub-batch alternate without rebuilding
+        std::vector<size_t> slot_data;                // the staged streams' slots the X-tile map was built from (compared by content: the key's slot_hash alone is a hash)
+    } tile_lists[8];   // eight slots: a batch's first, middle and last sub-batch alternate without rebuilding; a general hop takes two lists per launch shape
     int tile_list_next = 0;
     unsigned long long* d_clk = nullptr; size_t clk_cap = 0; int clk_n = 0;   // K-loop clock samples of the last profiled launch: 4 slots per sampled tile
     float4* d_E16 = nullptr;       // E in the B-operand order of the 16x16x4 GEMM: [column tile][k < hop / 2][n < 16]
@@ -2625,14 +2626,29 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             // so the middle sub-batches of a long stream share one list, and so do different buffers of one geometry)
             std::vector<BlockDftTables::SegKey> key = segs;
             if (!multi) key[0].pcm_off = key[0].out_row0 = key[0].fbeg = 0;
+            std::vector<size_t> slot_data;   // runs over a staged buffer: their slots by content (runs of one buffer share one slot list: taken once)
+            {
+                const Slot* seen = nullptr;
+                for (const Run& r : L) {
+                    const StreamIn& S = st[r.stream];
+                    if (!S.slots || S.slots == seen) continue;
+                    seen = S.slots;
+                    slot_data.push_back(S.n_slots);
+                    for (size_t i = 0; i < S.n_slots; ++i) {
+                        slot_data.push_back(S.slots[i].vframe0);
+                        slot_data.push_back(S.slots[i].n_frames);
+                        slot_data.push_back(S.slots[i].out_row0);
+                    }
+                }
+            }
             // kind 0: the tiles of a power-of-two hop (GEMM + tree); 1 / 2: the remainder / whole-block tiles of a general hop
             auto get_list = [&](int kind, BlockDftTables::TileList*& tl) -> pvq_status {
             tl = nullptr;
             for (auto& c : t->tile_lists)
-                if (c.bm == fused_bm && c.wide == wide_mode && c.multi == multi && c.kind == kind && c.key == key) tl = &c;
+                if (c.bm == fused_bm && c.wide == wide_mode && c.multi == multi && c.kind == kind && c.key == key && c.slot_data == slot_data) tl = &c;
             if (!tl) {
                 tl = &t->tile_lists[t->tile_list_next];
-                t->tile_list_next = (t->tile_list_next + 1) & 3;
+                t->tile_list_next = (t->tile_list_next + 1) & 7;
                 auto grp = [](const int4& e) { return e.x & 255; };
                 auto is_wide = [](const int4& e) { return ((e.x >> 8) & 1) != 0; };
                 auto seg_of = [](const int4& e) { return (int)((unsigned)e.x >> 16); };
@@ -2794,6 +2810,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 tl->d_segs = reinterpret_cast<const SegDev*>(dbase + b_list);
                 tl->d_xmap = reinterpret_cast<const XTile*>(dbase + b_list + b_segs);
                 tl->key = key;
+                tl->slot_data = slot_data;
                 tl->bm = fused_bm;
                 tl->wide = wide_mode;
                 tl->multi = multi;
@@ -2809,7 +2826,7 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 if (ls != PVQ_OK) return ls;
                 ls = get_list(2, tl);
                 if (ls != PVQ_OK) return ls;
-                // (the second lookup may have evicted the first: four slots, two lists per launch shape — look it up again)
+                // (the second lookup may have evicted the first — the slots are handed out round robin — look it up again)
                 ls = get_list(1, tl_r);
                 if (ls != PVQ_OK) return ls;
             } else {

@@ -211,9 +211,9 @@ def test_gemm_precision_switch_on_one_handle():
 
 
 def test_tile_list_cache_evicts_and_rebuilds_under_work_in_flight():
-    """ONE handle walked through nine distinct launch shapes and back, without a synchronisation between the calls: (frames, lead,
+    """ONE handle walked through twelve distinct launch shapes and back, without a synchronisation between the calls: (frames, lead,
     stream length, GEMM arithmetic, single stream / several streams, power-of-two / general hop).  The fused kernels' tile lists —
-    which tiles lie wholly inside their stream and may take 16-byte loads / pair up — are cached in four slots keyed on exactly that
+    which tiles lie wholly inside their stream and may take 16-byte loads / pair up — are cached in eight slots keyed on exactly that
     geometry, so this sequence evicts and rebuilds lists while earlier launches are still queued.  Round 3's in-round GPU fault
     ("The tile-list fault of round 3") was a list reused for a geometry it was not built for; here every call must give
     the bits a FRESH handle gives for the same shape, on the first pass and on the way back."""
@@ -222,6 +222,7 @@ def test_tile_list_cache_evicts_and_rebuilds_under_work_in_flight():
     shapes = [  # (frames, lead, arithmetic, n_streams, hop)
         (3000, 0, P.GEMM_F32, 1, 256), (3000, 16128, P.GEMM_F32, 1, 256), (1000, 0, P.GEMM_F32, 1, 256), (1000, 500, P.GEMM_BF16X3, 1, 256),
         (5000, 0, P.GEMM_F32, 1, 256), (3000, 0, P.GEMM_BF16X3, 1, 256), (700, 123, P.GEMM_F32, 3, 256), (2999, 0, P.GEMM_F32, 1, 256),
+        (4000, 0, P.GEMM_F32, 1, 256), (2000, 300, P.GEMM_F32, 1, 256), (1500, 0, P.GEMM_BF16X3, 1, 256),
         (600, 77, P.GEMM_F32, 1, 1600),
     ]
     pcms = {}
@@ -238,7 +239,7 @@ def test_tile_list_cache_evicts_and_rebuilds_under_work_in_flight():
 
     v = P.Vqt.new(pp, 0)
     v.set_algo(P.ALGO_BLOCKDFT)
-    order = list(range(len(shapes))) + list(range(len(shapes) - 1, -1, -1)) + [0, 4, 1, 6, 8, 3]
+    order = list(range(len(shapes))) + list(range(len(shapes) - 1, -1, -1)) + [0, 4, 1, 6, 11, 3, 9]
     outs = []
     for i in order:   # no synchronisation in between: the next call's list upload meets the previous launches still in flight
         o = torch.full((shapes[i][3], shapes[i][0], v.n_bins), -1.0, device="cuda")
