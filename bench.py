@@ -278,10 +278,17 @@ def main():
             km = vqt.last_kernel_ms()
             clk = vqt.last_sclk_mhz()   # shader clock inside the dominant kernel's K loop, sampled in the region's last launch
             vqt.set_profiling(False)
+            per_rank = [[dt_, float(clk), float(km.get("blockdft_gemm", 0.0))]]
             if world > 1:
-                t = torch.tensor([dt_], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+                dev_ = "cuda" if args.backend == "nccl" else "cpu"
+                mine = torch.tensor(per_rank[0], device=dev_, dtype=torch.float64)
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)   # (after the timed region: every rank's own clock around the same K steps, its sampled shader clock, its dominant kernel)
+                per_rank = [[float(x) for x in e.tolist()] for e in every]
+                t = torch.tensor([dt_], device=dev_, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_ = float(t.item())
+            timed_region.per_rank = per_rank
             return dt_, km, clk
 
         # the window a cold device gives (the first thing this process measures on it) ...
@@ -296,6 +303,7 @@ def main():
             dt, kernel_ms_main, clk_main = timed_region()
         else:
             dt, kernel_ms_main, clk_main = dt_cold, km_cold, clk_cold
+        per_rank = timed_region.per_rank
         # (kernel_ms_main: the dominant kernel, measured inside the timed region)
         # every kernel of a step, in an extra untimed pass of the same steps
         vqt.set_profiling(True)
@@ -308,7 +316,7 @@ def main():
         r = dict(vqt=vqt, shard=shard, n_bins=n_bins, F=F, kernel_ms=kernel_ms, kernel_n=kernel_n, fpl=vqt.last_frames_per_launch(),
                  gemm_flop=vqt.last_gemm_flop(),     # flop the matrix instructions of one GEMM launch issue (tiles x 256 x 64 x depth x 2)
                  sclk_mhz=clk_main,                  # shader clock inside the GEMM kernel's K loop, sampled during the timed launches
-                 dt_cold=dt_cold, km_cold=km_cold, clk_cold=clk_cold,
+                 dt_cold=dt_cold, km_cold=km_cold, clk_cold=clk_cold, per_rank=per_rank,
                  algo=vqt.last_algo())
         vqt.set_profiling(False)
         if with_alt:
@@ -366,6 +374,7 @@ def main():
         # profiles/traffic_latest.json with the hash of the kernel sources it measured).  It is attached only when that hash is the
         # hash of the library running now — a capture of an older build is named, not used.
         traffic, traffic_source = None, None
+        busy_frac, gui_cycles, counters_source = None, None, None   # the same capture's SQ counters: the matrix pipe's busy fraction and the kernel's active cycles (clock-independent)
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -375,6 +384,8 @@ def main():
                         if tj.get("srchash") == now:
                             traffic = tj.get("hbm_bytes_per_launch")
                             traffic_source = f"{tj.get('file')} (kernel sources {now[:12]}, the running build)"
+                            busy_frac, gui_cycles = tj.get("mfma_busy_frac"), tj.get("gui_active_cycles")
+                            counters_source = f"{tj.get('sq_file')} (kernel sources {now[:12]}, the running build)" if busy_frac is not None else None
                         else:
                             traffic_source = f"stale: {tj.get('file')} measured kernel sources {str(tj.get('srchash'))[:12]}, running {now[:12]}"
             except Exception as e:   # a malformed capture file must not take the bench line down
@@ -418,6 +429,11 @@ def main():
                 "frac": round(achieved / peak, 5),
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                # rocprofv3 SQ counters of the same capture (scripts/collect_profiles.sh), in CYCLES — what rounds are compared in, whatever clock a box holds:
+                # SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8), and GRBM_GUI_ACTIVE per launch (sum over the 8 XCDs)
+                "mfma_busy_frac": busy_frac,
+                "gui_active_cycles": gui_cycles,
+                "counters_source": counters_source,
                 "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
                 "executed_flop_per_launch": gemm_flop if exec_tflops is not None else None,
                 # the FFT-route count of SURVEY 8d for the same frames, kept apart: the block-DFT path does not execute it
@@ -491,6 +507,10 @@ def main():
                 "note": "same run, its own timed region (barrier + synchronize on both sides, max over ranks); scaling efficiency of "
                         "this workload = its value at N / (N x its value at N = 1, reported as config2_single_gpu in the N = 1 line)",
             }
+        if world > 1:
+            # every rank's own view of the timed region (`value` uses the slowest): a slow rank shows here instead of hiding in the max
+            out["per_rank"] = [{"rank": i, "ms_per_step": round(r_[0] / args.steps * 1e3, 4), "sclk_mhz": round(r_[1], 1),
+                                "dominant_kernel_ms_per_launch": round(r_[2], 4)} for i, r_ in enumerate(R["per_rank"])]
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -59,6 +59,9 @@ struct AbArgs {
     unsigned scratch_bytes;   // per-wave scratch of the peak routines: max(peaks_scratch_bytes, peaks_lean_scratch_bytes)
     unsigned wave_bytes;      // LDS bytes per wave
     int generic_peaks;        // developer build: 1 = the generic peak routine for every frame (A/B against the lean one)
+    // calmness.rs:40: the peaks of the RAW frames depend on the input alone, not on the recurrence: found for all frames of all streams at
+    // once by the frame kernels before this kernel starts (launch_peaks_frames), [stream][frame][words] bit masks
+    const uint32_t* raw_mask;
 };
 
 namespace {
@@ -86,12 +89,13 @@ __device__ __forceinline__ void ab_wave_sync() {
 __device__ __forceinline__ float ab_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 }  // namespace
 
-// LDS of one wave: two frame rows with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into
-// them), a per-bin row of amplitude weights, the frame's continuous peaks and their accuracy / deviation (npad / 2 each), flags,
-// the compacted list of flagged bins, the peak routines' scratch and the lean routine's peak list
+// LDS of one wave: the smoothed frame's row with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into
+// them), a scratch row (the amplitude weights of the flagged bins, then the per-bin peak indices of the pitch rows), the frame's
+// continuous peaks and their accuracy / deviation (npad / 2 each), flags, the compacted list of flagged bins, the raw frame's peak
+// mask words, the peak routines' scratch and the lean routine's peak list
 __host__ __device__ inline unsigned ab_wave_bytes(int n_bins, unsigned scratch_bytes) {
     const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
-    return (unsigned)((sizeof(float) * (2 * (npad + 2 * PK_PAD) + npad + 4 * (npad / 2)) + npad /*flags*/ + 2 * npad /*flagged bins: npad u16*/ +
+    return (unsigned)((sizeof(float) * ((npad + 2 * PK_PAD) + npad + 4 * (npad / 2)) + npad /*flags*/ + 2 * npad /*flagged bins: npad u16*/ + 4 * 32 /*mask words*/ +
                        scratch_bytes + npad /*lean peak list: npad / 2 u16*/ + 15) / 16 * 16);
 }
 
@@ -113,37 +117,32 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
     ps.mask = (a.o.peak_mask && s < a.n_streams) ? a.o.peak_mask + (size_t)s * a.n_frames * words : nullptr;
     ps.count = (a.o.peak_count && s < a.n_streams) ? a.o.peak_count + (size_t)s * a.n_frames : nullptr;
     ps.center = nullptr; ps.size = nullptr; ps.max_peaks = 0;
-    PeakParamsDev pg = ps;   // calmness.rs:40: the general config on the whole raw frame
-    pg.bass_min_prominence = a.peak_prom; pg.bass_min_height = a.peak_h;
-    pg.mask = nullptr; pg.count = nullptr;
 
-    // workgroup-shared: the per-bin thresholds of the lean routine's candidate test, for the two configurations
-    float* thr = reinterpret_cast<float*>(ab_lds);   // [4][npad]: H, P of the split configuration, H, P of the general one
+    // workgroup-shared: the per-bin thresholds of the lean routine's candidate test (the bass / general split configuration)
+    float* thr = reinterpret_cast<float*>(ab_lds);   // [2][npad]: H, P
     peaks_lean_thresholds(thr, thr + npad, ps, tid, 256);
-    peaks_lean_thresholds(thr + 2 * npad, thr + 3 * npad, pg, tid, 256);
     __syncthreads();
     if (s >= a.n_streams) return;   // (no workgroup barrier below: waves are independent)
 
-    unsigned char* base = ab_lds + (size_t)4 * npad * sizeof(float) + (size_t)wave * a.wave_bytes;
+    unsigned char* base = ab_lds + (size_t)2 * npad * sizeof(float) + (size_t)wave * a.wave_bytes;
     float* rowA = reinterpret_cast<float*>(base) + PK_PAD;      // the smoothed frame (find_peaks input), +INF on both sides
-    float* rowB = rowA + npad + 2 * PK_PAD;                     // the raw frame
-    float* pw = rowB + npad + PK_PAD;                           // 10^(dB / 10) of the bins around a raw peak
-    float* pc_c = pw + npad;                                    // peaks_continuous of the frame: center, size (npad / 2 each)
+    float* rowB = rowA + npad + PK_PAD;                         // scratch row: amplitude weights of the flagged bins, then the pitch rows' peak indices
+    float* pw = rowB;                                           // 10^(dB / 10) of the bins around a raw peak
+    float* pc_c = rowB + npad;                                  // peaks_continuous of the frame: center, size (npad / 2 each)
     float* pc_s = pc_c + npad / 2;
     float* pk_acc = pc_s + npad / 2;                            // ... and their pitch accuracy / deviation
     float* pk_dev = pk_acc + npad / 2;
     unsigned char* flag = reinterpret_cast<unsigned char*>(pk_dev + npad / 2);   // is-peak / around-a-raw-peak flags
     uint16_t* flist = reinterpret_cast<uint16_t*>(flag + npad);                  // compacted lists: bass peaks, then flagged bins (room for npad)
-    unsigned char* scratch = reinterpret_cast<unsigned char*>(flist + npad);     // the peak routines' scratch
+    uint32_t* mwords = reinterpret_cast<uint32_t*>(flist + npad);                // the raw frame's peak mask (32 words)
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(mwords + 32);      // the peak routines' scratch
     uint16_t* plist_lean = reinterpret_cast<uint16_t*>(scratch + a.scratch_bytes);
     const uint16_t* plist_gen = reinterpret_cast<const uint16_t*>(scratch + npad);   // where peaks_wave_nk leaves its list
-    for (int i = lane; i < PK_PAD; i += 64) {   // sentinels of both rows (the frame's own tail up to npad follows below, once)
-        rowA[-PK_PAD + i] = INF; rowB[-PK_PAD + i] = INF;
-        rowA[npad + i] = INF; rowB[npad + i] = INF;
+    for (int i = lane; i < PK_PAD; i += 64) {   // sentinels (the frame's own tail up to npad follows below, once)
+        rowA[-PK_PAD + i] = INF;
+        rowA[npad + i] = INF;
     }
-    for (int i = n + lane; i < npad; i += 64) {
-        rowA[i] = INF; rowB[i] = INF;
-    }
+    for (int i = n + lane; i < npad; i += 64) rowA[i] = INF;
 
     // find_peaks of one frame row: the lean routine, or — a plateau of three or more samples somewhere in the frame, or the
     // developer switch — the generic one; returns where the peak list (ascending bins, u16) was left
@@ -186,6 +185,8 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
     float xn[NK];   // the next frame's values, fetched a frame ahead
 #pragma unroll
     for (int k = 0; k < NK; ++k) xn[k] = (lane + 64 * k < n && a.n_frames > 0) ? db_s[lane + 64 * k] : 0.0f;
+    const uint32_t* rm_s = a.raw_mask + (size_t)s * a.n_frames * words;
+    uint32_t mw_next = (lane < words && a.n_frames > 0) ? rm_s[lane] : 0u;   // ... and its raw-peak mask word (lane < words <= 32)
 
     for (int f = 0; f < a.n_frames; ++f) {
         const size_t fr = (size_t)s * a.n_frames + f;
@@ -215,9 +216,10 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
                     y_sm[k] = y_sm[k] + alpha * (x - y_sm[k]);
                 }
                 rowA[bin] = y_sm[k];
-                rowB[bin] = x;
             }
         }
+        if (lane < 32) mwords[lane] = mw_next;
+        if (lane < words && f + 1 < a.n_frames) mw_next = rm_s[(size_t)(f + 1) * words + lane];
         ab_wave_sync();
         // ---- analysis.rs:332-349: peaks of the smoothed frame (mask / count go straight to the outputs)
         uint32_t total = 0;
@@ -354,19 +356,9 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
             tuning = tuning + alpha_t * (100.0f * avg - tuning);
         }
         ab_wave_sync();
-        // ---- calmness.rs:23-95: peaks of the RAW frame mark the bins "around a note"
-        uint32_t total_raw = 0;
-        const uint16_t* plist_raw = find_peaks_row(rowB, thr + 2 * npad, thr + 3 * npad, pg, f, total_raw);
-        ab_wave_sync();
-        for (int k = 0; k < NK; ++k)
-            if (lane + 64 * k < npad) flag[lane + 64 * k] = 0;
-        ab_wave_sync();
-        for (uint32_t idx = lane; idx < total_raw; idx += 64) {
-            const int p = plist_raw[idx];
-            const int lo = max(0, p - a.radius), hi = min(n, p + a.radius);
-            for (int i = lo; i < hi; ++i) flag[i] = 1;
-        }
-        ab_wave_sync();
+        // ---- calmness.rs:23-95: the peaks of the RAW frame (found before this kernel started: raw_mask) mark the bins "around a note":
+        //      peak p flags [max(0, p - radius), min(n, p + radius)), i.e. bin i is flagged iff one of the bins i - radius + 1 ... i + radius is a peak
+        auto raw_peak = [&](int p) { return p >= 0 && p < n && ((mwords[p >> 5] >> (p & 31)) & 1u) != 0; };
         // amplitude weights 10^(dB / 10) of the flagged bins only (a handful per frame): compacted, one lane per flagged bin
         bool fl[NK];
         {
@@ -374,7 +366,9 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int bin = lane + 64 * k;
-                fl[k] = bin < n && flag[bin] != 0;
+                bool any = false;
+                for (int p = bin - a.radius + 1; p <= bin + a.radius; ++p) any |= raw_peak(p);
+                fl[k] = bin < n && any;
                 const unsigned long long bmk = __ballot(fl[k]);
                 if (fl[k]) flist[n_fl + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)bin;
                 n_fl += __popcll(bmk);
@@ -478,6 +472,7 @@ AnalysisBatch::~AnalysisBatch() {
     if (d_times_) (void)hipFree(d_times_);
     if (d_tab_) (void)hipFree(d_tab_);
     if (d_frames_) (void)hipFree(d_frames_);
+    if (d_raw_) (void)hipFree(d_raw_);
 }
 
 pvq_status AnalysisBatch::frames_buffer(size_t bytes, float** out) {
@@ -674,8 +669,30 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     a.scratch_bytes = (unsigned)((std::max(peaks_scratch_bytes(a.n_bins, a.dist), peaks_lean_scratch_bytes(a.n_bins, a.dist)) + 15) / 16 * 16);
     a.wave_bytes = ab_wave_bytes(a.n_bins, a.scratch_bytes);
     a.generic_peaks = dev_knob("PVQ_AB_GENERIC", 0);
+    {   // the raw frames' peaks (calmness.rs:40: the general configuration on the whole frame), every frame of every stream at once
+        const size_t rows = (size_t)n_streams_ * n_frames, words = (size_t)(a.n_bins + 31) / 32;
+        const size_t need = rows * words * sizeof(uint32_t) + rows;   // masks, then the frame kernels' redo flags
+        if (raw_cap_ < need) {
+            if (d_raw_) PVQ_HIP(hipFree(d_raw_));   // (synchronises the device: nothing still reads the old buffer)
+            d_raw_ = nullptr;
+            raw_cap_ = 0;
+            PVQ_HIP(hipMalloc(&d_raw_, need));
+            raw_cap_ = need;
+        }
+        PeakParamsDev pg{};
+        pg.n_bins = a.n_bins; pg.bpo = a.bpo; pg.min_freq = a.min_freq; pg.lnf = a.lnf;
+        pg.peak_min_prominence = a.peak_prom; pg.peak_min_height = a.peak_h;
+        pg.bass_min_prominence = a.peak_prom; pg.bass_min_height = a.peak_h;
+        pg.highest_bassnote = a.highest_bassnote; pg.harmonic_threshold = a.harm_thr;
+        pg.dist = a.dist; pg.min_bin = a.min_bin;
+        pg.mask = static_cast<uint32_t*>(d_raw_);
+        pg.count = nullptr; pg.center = nullptr; pg.size = nullptr; pg.max_peaks = 0;
+        pvq_status ps = launch_peaks_frames(d_db, rows, pg, reinterpret_cast<uint8_t*>(static_cast<uint32_t*>(d_raw_) + rows * words), stream);
+        if (ps != PVQ_OK) return ps;
+        a.raw_mask = static_cast<const uint32_t*>(d_raw_);
+    }
     const dim3 grid((n_streams_ + 3) / 4);
-    const size_t lds = (size_t)4 * npad * sizeof(float) + (size_t)a.wave_bytes * 4;
+    const size_t lds = (size_t)2 * npad * sizeof(float) + (size_t)a.wave_bytes * 4;
     auto launch = [&](auto kern) -> pvq_status {
         PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);

@@ -77,6 +77,8 @@ class AnalysisBatch {
     size_t tab_cap_ = 0;
     void* d_frames_ = nullptr;         // dB frames of pvq_analysis_batch_preprocess_pcm
     size_t frames_cap_ = 0;
+    void* d_raw_ = nullptr;            // peak masks of the raw frames of the running call (frame-parallel pre-pass), then its scratch flags
+    size_t raw_cap_ = 0;
     std::vector<float> tab_host_;      // what d_tab_ holds (constant frame time: reused by the next call without an upload)
 };
 

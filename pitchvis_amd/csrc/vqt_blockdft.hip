@@ -985,6 +985,286 @@ __global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// THREE workgroups per CU (round 5; DESIGN.md 5.2 "(i)").  The 256 x 32 tile's life is a serial chain of latencies of which the K loop
+// is about a third; two such lives per CU leave the matrix pipe idle whenever both are outside their K loops.  This form buys a third
+// life with registers and LDS instead of a longer K share per life: at most 80 registers (6 waves per SIMD) and 38 KB of LDS, so
+//   * the K loop keeps ONE operand buffer per 16-row tile, fetched one stage (row tile x double k group = 32 MFMAs) ahead — the wide
+//     loop's scheme on one column tile: 32 accumulator + 32 operand registers;
+//   * the P' tile goes through LDS in two 16-column QUARTERS ([256 + 15][17] complex = 36.9 KB), one after the other through the same
+//     buffer (the second waits in its 16 accumulator registers), each with the doubling tree and the store of its own.
+// Every accumulator adds the same products in the same order as in the other K loops, every tree level is the same tree_cmadd: a
+// frame's bits do not depend on which form computed it (tests/test_configs_gpu.py::test_tile_shapes_bit_identical_in_subprocesses).
+// ------------------------------------------------------------------------------------------------
+constexpr int Q_C = 16;            // complex columns of a P quarter
+constexpr int Q_LDP = Q_C + 1;     // its row stride in LDS
+template <int BM, bool HALF>
+__device__ __forceinline__ void fused_f32_kloop16s(const GemmTreeArgs& a, const float* pcm_base, unsigned pcm_bytes, float* smem, long long tile_lo, const float4* e_tile, int tid,
+                                                   f32x4a (&accR)[2][2], f32x4a (&accI)[2][2], const float* tw_src, float* tw_dst, int tw_levels, int tw_stride, int stamp_slot) {
+    constexpr int THREADS = 2 * BM, NWV = THREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
+    const unsigned long long pcm_addr = reinterpret_cast<unsigned long long>(pcm_base);
+    const i32x4 rsrc4 = {(int)(unsigned)pcm_addr, (int)(unsigned)(pcm_addr >> 32), (int)pcm_bytes, 0x00020000};
+    const int K2 = a.K / 2;
+    const int nG = K2 / 32;
+    // one byte offset per lane and direction (row tile 0); row tile 1 lies 16 rows = 16 K samples further on: that, the double group and
+    // the half ride in the instruction's SCALAR offset
+    const long long row_lo = tile_lo + (long long)(wave * 32 + m16) * a.K;
+    const unsigned vf = (unsigned)((row_lo + 8 * kq) * 4ll);
+    const unsigned vb = (unsigned)((row_lo + a.K - 8 - 8 * kq) * 4ll) - 128u * (unsigned)(nG - 1);
+    const int mt_step = 64 * a.K;   // bytes between the two row tiles of a wave
+    float fr[2][8], bk[2][8];
+    auto load_stage = [&](int mt, int G) {   // unconditional, clamped (see fused_f32_kloop16)
+        const int Gc = G < nG - 1 ? G : nG - 1;
+        const int sf = 128 * Gc + mt * mt_step, sb = 128 * (nG - 1 - Gc) + mt * mt_step;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 v = pvq_raw_buffer_load_f32x4(rsrc4, (int)vf, sf + 16 * h, 0);
+            const f32x4 w = pvq_raw_buffer_load_f32x4(rsrc4, (int)vb, sb + 16 * h, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fr[mt][4 * h + t] = v[t];
+                bk[mt][4 * h + t] = w[t];
+            }
+        }
+    };
+    float4* El = reinterpret_cast<float4*>(smem);   // [rows][16]
+    const float4* erow = El + (8 * kq) * 16 + m16;
+    auto b_at = [&](int Gl, int r) { return erow[(32 * Gl + r) * 16]; };
+    // one stage: the 8 k rows of a double group for one 16-row tile, 4 MFMAs each, the B operand fetched one row ahead
+    auto mfma_stage = [&](int mt, int Gl, int Gl_next, float4 bc) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float4 bn = r < 7 ? b_at(Gl, r + 1) : b_at(Gl_next, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const float sm = fr[mt][r] + bk[mt][7 - r];
+            const float df = fr[mt][r] - bk[mt][7 - r];
+            accR[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, bc.x, accR[mt][0], 0, 0, 0);
+            if (!HALF) accR[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm, bc.y, accR[mt][1], 0, 0, 0);
+            accI[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, bc.z, accI[mt][0], 0, 0, 0);
+            if (!HALF) accI[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(df, bc.w, accI[mt][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bc = bn;
+        }
+        return bc;
+    };
+    auto stage_e = [&](int kc, int rows) {
+        constexpr int FULL = FR_KC / 4 / NWV;
+        const float4* src = e_tile + (size_t)kc * 16 + wave * 64 + lane;
+        float4* dst = El + wave * 64;
+        if (rows == FR_KC && FR_KC / 4 % NWV == 0) {
+#pragma unroll
+            for (int q = 0; q < FULL; ++q) lds_dma16(src + q * (NWV * 64), dst + q * (NWV * 64));
+        } else {
+            for (int j = wave; j < rows / 4; j += NWV) lds_dma16(e_tile + (size_t)kc * 16 + j * 64 + lane, El + j * 64);
+        }
+    };
+    stage_e(0, K2 < FR_KC ? K2 : FR_KC);
+    for (int l = wave; l < tw_levels; l += NWV) lds_dma4(tw_src + (size_t)l * tw_stride, tw_dst + l * (2 * CB_C));
+    load_stage(0, 0);
+    load_stage(1, 0);
+    __syncthreads();
+    PVQ_STAMP(7);
+    for (int kc = 0; kc < K2; kc += FR_KC) {
+        const int rows = K2 - kc < FR_KC ? K2 - kc : FR_KC;
+        if (kc > 0) {
+            __syncthreads();
+            stage_e(kc, rows);
+            __syncthreads();
+        }
+        const int ng = rows / 32, G0 = kc / 32;
+        float4 bc = b_at(0, 0);
+        for (int Gl = 0; Gl < ng; ++Gl) {
+            bc = mfma_stage(0, Gl, Gl, bc);
+            load_stage(0, G0 + Gl + 1);
+            bc = mfma_stage(1, Gl, Gl + 1, bc);
+            load_stage(1, G0 + Gl + 1);
+        }
+    }
+}
+
+// the 16 columns NP of the accumulators -> LDS as [row][16 complex + pad], the 15 spare rows zeroed
+template <int BM>
+__device__ __forceinline__ void q_dump_p(float* smem, const f32x4a (&accR)[2][2], const f32x4a (&accI)[2][2], int np, int tid) {
+    float2 (*Pt)[Q_LDP] = reinterpret_cast<float2 (*)[Q_LDP]>(smem);
+    const int lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Pt[wave * 32 + mt * 16 + 4 * kq + r][m16] = np == 0 ? make_float2(accR[mt][0][r], accI[mt][0][r]) : make_float2(accR[mt][1][r], accI[mt][1][r]);
+    for (int i = tid; i < 15 * Q_LDP; i += 2 * BM) Pt[BM][i] = make_float2(0.0f, 0.0f);
+}
+// the first R <= 4 tree levels in registers: a thread owns 8 consecutive rows of one of the quarter's 16 columns (+ the 2^R - 1 rows above)
+template <int R, int BM>
+__device__ __forceinline__ void q_tree_register_levels(float2 (*A)[Q_LDP], const float2 (*tw)[CB_C], int cq, int tid) {
+    constexpr int H = (1 << R) - 1;
+    constexpr int RPT = BM * Q_C / (2 * BM);   // 8 rows per thread
+    const int c = tid & (Q_C - 1), j0 = (tid >> 4) * RPT;
+    float2 v[RPT + H];
+#pragma unroll
+    for (int i = 0; i < RPT + H; ++i) v[i] = A[j0 + i][c];
+    int len = RPT + H;
+#pragma unroll
+    for (int l = 0; l < R; ++l) {
+        const int st = 1 << l;
+        const float2 w = tw[l][cq + c];
+        len -= st;
+#pragma unroll
+        for (int i = 0; i < RPT + H; ++i)
+            if (i < len) v[i] = tree_cmadd(v[i], w, v[i + st]);
+    }
+    __syncthreads();   // every thread has read its halo
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) A[j0 + i][c] = v[i];
+    __syncthreads();
+}
+// one quarter from the P' tile in LDS to X: the tree (same operations, level by level, as fused_tree_levels), then the store
+template <int BM>
+__device__ __forceinline__ void q_tree_store(float* smem, const float2 (*tw)[CB_C], const FusedTile& t, const GemmTreeArgs& a, int cq, int tid, int stamp_slot) {
+    float2 (*A)[Q_LDP] = reinterpret_cast<float2 (*)[Q_LDP]>(smem);
+    constexpr int THREADS = 2 * BM;
+    constexpr int PER = BM * Q_C / THREADS;  // 8
+    const int c = tid & (Q_C - 1);
+    const int levels = t.G.levels_f;
+    int l = levels < 4 ? levels : 4;
+    switch (l) {   // wave-uniform
+        case 1: q_tree_register_levels<1, BM>(A, tw, cq, tid); break;
+        case 2: q_tree_register_levels<2, BM>(A, tw, cq, tid); break;
+        case 3: q_tree_register_levels<3, BM>(A, tw, cq, tid); break;
+        case 4: q_tree_register_levels<4, BM>(A, tw, cq, tid); break;
+        default: break;
+    }
+    PVQ_STAMP(6);
+    int valid = BM - ((1 << l) - 1);
+    for (; l + 1 < levels; l += 2) {
+        const int st = 1 << l;
+        const float2 w1 = tw[l][cq + c], w2 = tw[l + 1][cq + c];
+        valid -= 3 * st;
+        float2 v[PER];
+#pragma unroll
+        for (int g = 0; g < PER; g += 4) {
+#pragma unroll
+            for (int q = g; q < g + 4; ++q) {
+                const int j = (tid + q * THREADS) / Q_C;
+                if (j < valid) {
+                    const float2 t0 = tree_cmadd(A[j][c], w1, A[j + st][c]);
+                    const float2 t1 = tree_cmadd(A[j + 2 * st][c], w1, A[j + 3 * st][c]);
+                    v[q] = tree_cmadd(t0, w2, t1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = (tid + q * THREADS) / Q_C;
+            if (j < valid) A[j][c] = v[q];
+        }
+        __syncthreads();
+    }
+    for (; l < levels; ++l) {
+        const int st = 1 << l;
+        valid -= st;
+        const float2 w = tw[l][cq + c];
+        float2 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = (tid + q * THREADS) / Q_C;
+            if (j < valid) v[q] = tree_cmadd(A[j][c], w, A[j + st][c]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = (tid + q * THREADS) / Q_C;
+            if (j < valid) A[j][c] = v[q];
+        }
+        __syncthreads();
+    }
+    PVQ_STAMP(2);
+    // store: lanes walk the frames of one column (512-byte runs)
+    const int j = tid % BM;
+    const int f = t.f0 + j;
+    if (j < t.S && f < t.nfr) {
+        const bool to_y = t.G.nb > t.G.nb_f;
+        float2* dst = (to_y ? a.Y : a.X) + ((size_t)((f >> 6) + (to_y ? t.yt0 : t.xt0)) * a.xcp + t.nt * CB_C + cq) * 64 + (f & 63);
+        int ncv = t.G.n_cols - t.ntl * CB_C - cq;   // the quarter's real columns
+        ncv = ncv < Q_C ? ncv : Q_C;
+#pragma unroll 4
+        for (int cc = tid / BM; cc < ncv; cc += 2) {
+            const float2 val = A[j][cc];
+            __builtin_nontemporal_store((f32x2){val.x, val.y}, reinterpret_cast<f32x2*>(&dst[cc * 64]));
+        }
+    }
+}
+
+template <int BM>
+__global__ __launch_bounds__(2 * BM, 6) void blockdft_gemm_tree3(GemmTreeArgs a) {   // 6 waves per SIMD = three 512-thread workgroups per CU: at most 80 registers
+    constexpr int B_FLOATS = FR_KC * FT_BN;
+    constexpr int P_FLOATS = (BM + 15) * Q_LDP * 2;
+    __shared__ __attribute__((aligned(16))) float smem[B_FLOATS > P_FLOATS ? B_FLOATS : P_FLOATS];  // the E slice, then a P quarter
+    __shared__ float2 tw_lds[FT_MAXL][CB_C];
+    const unsigned long long t_entry = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int4 entry = a.tile_list[blockIdx.x];   // .x: group | segment << 16 (no wide entries in this kernel's lists)
+    const TileStream ts = tile_stream(a, entry.x);
+    const FusedTile T = fused_tile_of<BM>(a, make_int4(entry.x & 7, entry.y, entry.z, entry.w), ts);
+    if (T.f0 >= T.nfr) return;
+    const int stamp_slot = blockIdx.x;
+    PVQ_STAMP(0);
+    const long long s = ts.base + T.G.s_rel;
+    const long long tile_lo = s + (long long)T.f0 * a.K, tile_hi = tile_lo + (long long)BM * a.K;
+    const bool inside = tile_lo >= 0 && tile_hi * 4ll <= (long long)ts.pcm_bytes;
+    const float* tw_src = reinterpret_cast<const float*>(a.comb_tw + T.G.tw_off + T.ntl * CB_C) + lane;
+    float* tw_dst = reinterpret_cast<float*>(&tw_lds[0][0]);
+    const int tw_levels = T.G.levels_f, tw_stride = 2 * T.G.n_tiles * CB_C;
+    const float4* e_tile = a.E16 + (size_t)T.nt * (a.K / 2) * 16;
+    f32x4a accR[2][2], accI[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accR[mt][np][r] = 0.0f;
+                accI[mt][np][r] = 0.0f;
+            }
+    if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
+        a.clk[(blockIdx.x >> 6) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        a.clk[(blockIdx.x >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    const bool half = T.ntl == T.G.n_tiles - 1 && T.G.n_cols - T.ntl * CB_C <= 16;
+    if (!inside)
+        fused_f32_kloop16_edge<BM>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot, a.K);
+    else if (half)
+        fused_f32_kloop16s<BM, true>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+    else
+        fused_f32_kloop16s<BM, false>(a, ts.pcm_base, ts.pcm_bytes, smem, tile_lo, e_tile, tid, accR, accI, tw_src, tw_dst, tw_levels, tw_stride, stamp_slot);
+    if (a.clk != nullptr && (blockIdx.x & 63) == 0 && tid == 0) {
+        a.clk[(blockIdx.x >> 6) * 4 + 2] = __builtin_amdgcn_s_memtime();
+        a.clk[(blockIdx.x >> 6) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+    PVQ_STAMP(1);
+    __syncthreads();   // the E slice is dead: the first P' quarter takes its place
+    PVQ_STAMP(4);
+    q_dump_p<BM>(smem, accR, accI, 0, tid);
+    __syncthreads();
+    PVQ_STAMP(5);
+    q_tree_store<BM>(smem, tw_lds, T, a, 0, tid, stamp_slot);
+    if (T.G.n_cols - T.ntl * CB_C > Q_C) {   // (a last tile of at most 16 columns has no second quarter)
+        __syncthreads();
+        q_dump_p<BM>(smem, accR, accI, 1, tid);
+        __syncthreads();
+        q_tree_store<BM>(smem, tw_lds, T, a, Q_C, tid, stamp_slot);
+    }
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        PVQ_STAMP(3);
+    }
+    PVQ_END_STAMPS
+}
+
+// ------------------------------------------------------------------------------------------------
 // General hops: a multiple of 64 samples that does NOT divide the windows (1 600 samples = 30 analyses per second at 48 kHz, the
 // cadence of pitchvis_serial/src/main.rs:41; the trainer's 3 x chunk, pitchvis_train/src/train.rs:43).  With W = nq hop + rem,
 //
@@ -1615,6 +1895,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
         rstep = xt.live_step >> 8;
         row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
         n_live = (xt.live_step & 255) - (f0 & 63);
+        if (n_live <= 0) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -1735,6 +2016,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
         rstep = xt.live_step >> 8;
         row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
         n_live = (xt.live_step & 255) - (f0 & 63);
+        if (n_live <= 0) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -1861,6 +2143,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
         rstep = xt.live_step >> 8;
         row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
         n_live = (xt.live_step & 255) - (f0 & 63);
+        if (n_live <= 0) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -2614,7 +2897,9 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             static const int pair_half_env = dev_knob("PVQ_PAIR_HALF", 0); // 1: a group's last tile of at most 16 columns pairs up too (measured: same time, more MFMAs)
             static const int tail_env = dev_knob("PVQ_TAIL", 128);       // narrow entries at the end of every queue
             static const int wide_env = dev_knob("PVQ_WIDE", 1);         // 0: narrow tiles only; 2: wide tiles to the very end of every queue; 3: none in a queue's last stripe
-            const int wide_mode = !use_bf && fused_bm == 256 && !t->general ? wide_env : 0;   // (the split-bf16 kernel, the 128-row form and the general-hop kernel take 32-column tiles only)
+            static const int tree3_env = dev_knob("PVQ_TREE3", 0);       // 1: blockdft_gemm_tree3 (three workgroups per CU, 32-column tiles, P' in 16-column quarters)
+            const bool tree3 = tree3_env && !use_bf && fused_bm == 256 && !t->general;
+            const int wide_mode = !use_bf && fused_bm == 256 && !t->general && !tree3 ? wide_env : 0;   // (the split-bf16 kernel, the 128-row form and the general-hop kernel take 32-column tiles only)
             if (segs.size() > 0xFFFFu) {
                 set_last_error("too many streams in one launch");
                 return PVQ_ERR_INTERNAL;
@@ -2893,6 +3178,8 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 d_xmap = multi ? tl->d_xmap : nullptr;
             } else if (use_bf)
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
+            else if (tree3)
+                hipLaunchKernelGGL(blockdft_gemm_tree3<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
             else

@@ -1499,6 +1499,14 @@ pvq_status Vqt::calculate_vqt_instant_in_db(const float* x, size_t len, float* o
 }
 
 pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const PeakParamsDev& a, hipStream_t stream) {
+    pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
+    if (st != PVQ_OK) return st;
+    return launch_peaks_frames(d_db, n_frames, a, static_cast<uint8_t*>(ws_flags_), stream);
+}
+
+// find_peaks over n_frames independent dB rows (the lean kernel, then the generic one over the few frames it flags in `redo`, n_frames bytes
+// of device scratch): the frame kernels of the batch path, also the frame-parallel pre-pass of AnalysisBatch (analysis_batch.hip)
+pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakParamsDev& a, uint8_t* redo, hipStream_t stream) {
     const int npad = (a.n_bins + 63) / 64 * 64;
     const size_t lds_gen = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
     // bins per lane: 4 (<= 256 bins), 8 (<= 512), 12 (<= 768) or 16 (<= 1024); the lean kernel also has 6 (<= 384)
@@ -1512,9 +1520,6 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
         else
             hipLaunchKernelGGL(peaks_frames_generic<16>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
     };
-    pvq_status st = ensure_workspace(&ws_flags_, &ws_flags_cap_, n_frames);
-    if (st != PVQ_OK) return st;
-    uint8_t* redo = static_cast<uint8_t*>(ws_flags_);
     const int sweep_grid = (int)std::min<size_t>(256, (n_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES));
     const int fpw = a.n_bins <= 384 ? 2 : 1;
     const size_t lds_lean = peaks_lean_lds_bytes(a.n_bins, a.dist, fpw, a.highest_bassnote);

@@ -209,6 +209,9 @@ pvq_status analyze_batch_multi(Vqt* const* handles, uint32_t n_handles, const fl
                                const AnalysisParameters& a, float* out_db, uint32_t* peak_mask, uint32_t* peak_count, float* center,
                                float* size, uint32_t max_peaks);
 
+// find_peaks over n_frames independent dB rows [n_frames][a.n_bins] (vqt_engine.hip; redo: n_frames bytes of device scratch)
+pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakParamsDev& a, uint8_t* redo, hipStream_t stream);
+
 void set_last_error(const std::string& s);
 void set_last_error_noexcept(const char* s) noexcept;   // for exception handlers: never throws (drops the text if it cannot be stored)
 const char* get_last_error();

@@ -56,9 +56,29 @@ for cfg, n_bins, fpl in ((1, 252, 65536), (2, 288, 131072)):
                                      "hbm_bytes_per_launch": round((2 * fe + wr) * 1024), "srchash": srchash,
                                      "file": f"profiles/{tag}_pmc_traffic{'' if cfg == 1 else '_config2'}.csv"})
     print(open(name).read())
+# cycles, not microseconds: the dominant kernels' matrix-pipe busy fraction and active cycles per launch (clock-independent: rounds compare in these)
+acc_sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"gpurun_out/{tag}_sq*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "pvq::" in r["Kernel_Name"] and "bf16x3" not in r["Kernel_Name"]:
+            acc_sq[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for cap in captures:
+    if cap["n_bins"] != 252:
+        continue   # (the SQ passes run configs[1])
+    d = acc_sq.get(cap["kernel_name"], {})
+    if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE"):
+        busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(d["SQ_VALU_MFMA_BUSY_CYCLES"])
+        gui = sum(d["GRBM_GUI_ACTIVE"]) / len(d["GRBM_GUI_ACTIVE"])
+        cap["mfma_busy_cycles"] = round(busy)
+        cap["gui_active_cycles"] = round(gui)            # summed over the 8 XCDs, as rocprofv3 reports it
+        cap["mfma_busy_frac"] = round(busy / (1024.0 * gui / 8.0), 4)   # 1 024 SIMDs x the kernel's cycles
+        if d.get("SQ_INSTS_MFMA"):
+            cap["insts_mfma"] = round(sum(d["SQ_INSTS_MFMA"]) / len(d["SQ_INSTS_MFMA"]))
+        cap["sq_file"] = f"profiles/{tag}_sq_counters.txt"
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB per launch, mean); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                    "on gfx950 FETCH_SIZE reports half the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM); srchash = sha256 of the "
-                   "kernel sources the measured library was built from (pitchvis_amd/lib/libpvq.so.srchash)",
+                   "kernel sources the measured library was built from (pitchvis_amd/lib/libpvq.so.srchash); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                   "gui_active_cycles = GRBM_GUI_ACTIVE per launch (sum over the 8 XCDs), both from separate --pmc passes of the same command",
            "captures": captures}, open("gpurun_out/traffic_latest.json", "w"), indent=1)
 st = glob.glob(f"gpurun_out/{tag}_stats/*/*kernel_stats.csv")[0]
 with open(f"gpurun_out/{tag}_kernel_stats.csv", "w") as f:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): rate of pvq_analysis_batch_preprocess_device over the number of streams (one wave owns a stream: the kernel
 is latency-bound per stream and scales with streams, not frames), 252 and 588 bins, default smoothing.
-usage: python3 scripts/dev_analysis_batch.py [out-file] [once]   (once: a single 4096-stream x 252-bin call, for rocprofv3)"""
+usage: python3 scripts/dev_analysis_batch.py [out-file] [once [bpo]]   (once: a single 4096-stream x 128-frame call at 7 x bpo bins, for rocprofv3)"""
 import os, sys
 import numpy as np
 import torch
@@ -53,8 +53,8 @@ def rate(bpo, octaves, n_streams, n_frames, reps=3, outputs="all"):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else None
-    if len(sys.argv) > 2 and sys.argv[2] == "once":
-        print(rate(36, 7, 4096, 128, reps=2))
+    if len(sys.argv) > 2 and sys.argv[2] == "once":   # once [bpo]: 36 -> 252 bins, 84 -> 588 bins (the reference's default geometry: NK = 10, distance rule)
+        print(rate(int(sys.argv[3]) if len(sys.argv) > 3 else 36, 7, 4096, 128, reps=2))
         sys.exit(0)
     lines = []
     quick = len(sys.argv) > 2 and sys.argv[2] == "quick"

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Developer tool (GPU box): rocprofv3 kernel stats + SQ counters of analysis_batch_preprocess (one 4096-stream x 128-frame x 252-bin call per pass).
-# usage: scripts/pmc_analysis_batch.sh <tag>     (the program goes directly after `--`)
+# Developer tool (GPU box): rocprofv3 kernel stats + SQ counters of analysis_batch_preprocess (one 4096-stream x 128-frame call per pass).
+# usage: scripts/pmc_analysis_batch.sh <tag> [bpo]     (bpo 36: 252 bins, 84: 588 bins; the program goes directly after `--`)
 TAG=${1:-ab}
+BPO=${2:-36}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/dev_analysis_batch.py - once > $OUT/stats.log 2>&1 || echo "stats pass failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/dev_analysis_batch.py - once $BPO > $OUT/stats.log 2>&1 || echo "stats pass failed"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
@@ -14,7 +15,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $ROOT/scripts/dev_analysis_batch.py - once > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $ROOT/scripts/dev_analysis_batch.py - once $BPO > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 cd $ROOT
 python3 - <<PY
@@ -26,7 +27,7 @@ for f in glob.glob("gpurun_out/$TAG/p*/*/*counter_collection.csv"):
             acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("gpurun_out/$TAG/summary.txt", "w") as out:
     for k, d in acc.items():
-        out.write(k + "   (one call: 4096 streams x 128 frames x 252 bins, every output)\n")
+        out.write(k + "   (one call: 4096 streams x 128 frames x 7 x $BPO bins, every output)\n")
         for c, v in sorted(d.items()):
             out.write(f"    {c:28s} {sum(v)/len(v):16.0f}  (n={len(v)})\n")
     st = glob.glob("gpurun_out/$TAG/stats/*/*kernel_stats.csv")

@@ -343,13 +343,14 @@ def test_tile_shapes_bit_identical_in_subprocesses():
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     res = {}
     for tag, env in (("base", {}), ("dev", {"PVQ_DEV_LIB": "1"}), ("bm128", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "128"}), ("bm256", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "256"}),
-                     ("narrow", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "0", "PVQ_BALANCE": "0"}), ("wide_all", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "2"})):
+                     ("narrow", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "0", "PVQ_BALANCE": "0"}), ("wide_all", {"PVQ_DEV_LIB": "1", "PVQ_WIDE": "2"}),
+                     ("tree3", {"PVQ_DEV_LIB": "1", "PVQ_FUSED_BM": "256", "PVQ_TREE3": "1"})):   # three workgroups per CU, P' in 16-column quarters (blockdft_gemm_tree3: measured, not adopted)   # three workgroups per CU, P' in 16-column quarters (blockdft_gemm_tree3)
         f = os.path.join(root, "gpurun_out", f"forms_{tag}.npz")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0 and "FORM_OK" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = dict(np.load(f))
         os.remove(f)
-    for tag in ("dev", "bm128", "bm256", "narrow", "wide_all"):
+    for tag in ("dev", "bm128", "bm256", "narrow", "wide_all", "tree3"):
         for k, a in res["base"].items():
             assert np.array_equal(a.view(np.uint32), res[tag][k].view(np.uint32)), (tag, k)
 
