@@ -25,6 +25,14 @@
 #include "device_tables.hpp"
 #include "peaks_device.hpp"
 
+// Every floating-point operation of this file rounds where it is written: no implicit FMA contraction.  The FFT path exists in several forms —
+// the walk (vqt_fft_frames, any window at run time, for four thread counts), its group-split launch for few frames, and one kernel per window
+// size for batches (vqt_fft_group) — and a frame must have the same bits whichever form computed it (a stream's values do not depend on the size
+// of the batch it is analysed in).  Left to contract on its own, the compiler fuses a product into a neighbouring addition or not depending on the
+// code around it: the same source, inlined into two kernels, rounded differently in 94 % of the coefficients (1.4e-7 of the frame peak;
+// profiles/r05_fft_path.txt).  Where a fused multiply-add is wanted it is written (fmaf): the same instructions in every form, by construction.
+#pragma clang fp contract(off)
+
 namespace pvq {
 
 // ------------------------------------------------------------------------------------------------
@@ -53,8 +61,8 @@ const char* get_last_error() { return g_last_error.c_str(); }
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {   // two products, two fused multiply-adds
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -278,7 +286,7 @@ __device__ __forceinline__ void db_epilogue(const float2* xv, float* red, int n_
         d[t] = 0.0f;
         if (k < n_bins) {
             const float2 z = xv[k];
-            const float ns = z.x * z.x + z.y * z.y;
+            const float ns = fmaf(z.x, z.x, z.y * z.y);
             bad |= !(ns <= 3.40282347e+38f);
             d[t] = 10.0f * log10f(fmaxf(ns, PVQ_A_MIN)) - ref_db;
             mx = fmaxf(mx, d[t]);
@@ -476,8 +484,8 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
                         for (int f = 0; f < F; ++f) {
                             float2 x = Z0[(size_t)f * per_frame + idx];
                             x.y *= sg;
-                            acc[f].x += en.x * x.x - en.y * x.y;
-                            acc[f].y += en.x * x.y + en.y * x.x;
+                            acc[f].x = fmaf(-en.y, x.y, fmaf(en.x, x.x, acc[f].x));
+                            acc[f].y = fmaf(en.y, x.x, fmaf(en.x, x.y, acc[f].y));
                         }
                     }
                     for (int o = tpr >> 1; o > 0; o >>= 1) {
@@ -510,6 +518,248 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_frames(FftArgs a) {   // fou
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The FFT path for BATCHES (round 5): one kernel instantiation per window size.  vqt_fft_frames above takes any window at run time:
+// every LDS address of its Stockham passes is computed from N, p and the thread's item (lpad, masks, multiplies), and of the ~330
+// vector instructions it spends per radix-16 item and pass two thirds are that index arithmetic.  Here N, the pass stride P and the
+// threads per frame T = N / 16 are template parameters: an item's 16 reads and 16 writes are ONE base address plus immediates, the
+// pass chain is unrolled, and a workgroup serves one window group (the launch is per group, as the few-frames form of the kernel
+// above already is: rows of x_vqt through `xv_split`, db_rows finishes the frames).  The arithmetic is the walk's — the same twiddle
+// table entries, the same cmul and RegFft<R>, the same pass radices and pruning, the same real split and row dots with the same
+// lanes-per-row — so a frame's bits are what vqt_fft_frames gives (tests/test_parity_gpu.py::test_fft_batch_kernels_equal_the_walk).
+// ------------------------------------------------------------------------------------------------
+template <int R, int N, int P, int T>
+__device__ __forceinline__ void stockham_pass_ct(float2* __restrict__ Z, const float2* __restrict__ tw, int n_tw, int tl) {
+    constexpr int NB = 16 / R;            // items per thread: NB * T = N / R exactly
+    constexpr int TI = N / R;             // items of the pass
+    static_assert(TI % 16 == 0 && NB * T == TI, "pass geometry");
+    constexpr int LTI = TI + TI / 16;     // lpad(i + r TI) = lpad(i) + r LTI
+    float2 u[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float2* zi = Z + lpad(tl + b * T);
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[b][r] = zi[r * LTI];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (P > 1) {
+            const int k = (tl + b * T) & (P - 1);
+            const int base = k * (n_tw / (P * R));
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[b][r] = cmul(u[b][r], tw[base * r]);
+        }
+        RegFft<R>::run(u[b]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tl + b * T;
+        const int k = i & (P - 1);
+        const int j = (i - k) * R + k;
+        if (P >= 16) {   // lpad(j + r P) = lpad(j) + r (P + P / 16)
+            float2* zj = Z + lpad(j);
+#pragma unroll
+            for (int r = 0; r < R; ++r) zj[r * (P + P / 16)] = u[b][r];
+        } else {         // the first pass (P = 1, R = 16): j = 16 i, lpad(j + r) = 17 i + r
+            static_assert(P >= 16 || (P == 1 && R == 16), "first pass");
+            float2* zj = Z + 17 * i;
+#pragma unroll
+            for (int r = 0; r < R; ++r) zj[r] = u[b][r];
+        }
+    }
+    __syncthreads();
+}
+template <int R, int N, int P, int T>
+__device__ __forceinline__ void stockham_pass_ends_ct(float2* __restrict__ Z, const float2* __restrict__ tw, int n_tw, int tl, int M) {
+    constexpr int NB = 16 / R;
+    constexpr int TI = N / R;
+    constexpr int LTI = TI + TI / 16;
+    static_assert(P >= 16, "a pruned pass is never the first");
+    float2 lo[NB], hi[NB];
+    bool nl[NB], nh[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tl + b * T;
+        const int k = i & (P - 1);
+        nl[b] = k <= M;
+        nh[b] = k >= P - M;
+        lo[b] = make_float2(0.0f, 0.0f);
+        hi[b] = lo[b];
+        if (nl[b] || nh[b]) {
+            float2 u[R];
+            const float2* zi = Z + lpad(i);
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = zi[r * LTI];
+            const int base = k * (n_tw / (P * R));
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[base * r]);
+            float2 s0 = u[0], s1 = u[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                constexpr int step = 16 / R;
+                const int idx = r * step;   // e^{+2 pi i idx / 16}
+                const float c = idx < 8 ? kC16[idx] : -kC16[idx - 8], sn = idx < 8 ? kS16[idx] : -kS16[idx - 8];
+                s0 = cadd(s0, u[r]);
+                s1 = cadd(s1, cmul(u[r], make_float2(c, sn)));
+            }
+            lo[b] = s0;
+            hi[b] = s1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tl + b * T;
+        const int k = i & (P - 1);
+        float2* zj = Z + lpad((i - k) * R + k);
+        if (nl[b]) zj[0] = lo[b];
+        if (nh[b]) zj[(R - 1) * (P + P / 16)] = hi[b];
+    }
+    __syncthreads();
+}
+// the pass chain of lds_fft for a compile-time N: radix 16 while 16 or more points remain, then one pass of radix 8, 4 or 2
+template <int N, int P, int T>
+__device__ __forceinline__ void lds_fft_ct(float2* Z, const float2* tw, int n_tw, int tl, int M) {
+    constexpr int REM = N / P;
+    if constexpr (REM >= 16) {
+        if (M < P) {
+            if constexpr (P >= 16) stockham_pass_ends_ct<16, N, P, T>(Z, tw, n_tw, tl, M);
+        } else {
+            stockham_pass_ct<16, N, P, T>(Z, tw, n_tw, tl);
+        }
+        lds_fft_ct<N, P * 16, T>(Z, tw, n_tw, tl, M);
+    } else if constexpr (REM > 1) {
+        if (M < P) stockham_pass_ends_ct<REM, N, P, T>(Z, tw, n_tw, tl, M);
+        else stockham_pass_ct<REM, N, P, T>(Z, tw, n_tw, tl);
+    }
+}
+
+template <int N, int BLOCK>   // N complex points (a window of 2 N samples), T = N / 16 threads per frame, F = BLOCK / T frames per workgroup side by side
+__global__ __launch_bounds__(BLOCK, 4) void vqt_fft_group(FftArgs a, int g, int frame0, int n_frames_here) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = N / 16, F = BLOCK / T;
+    constexpr int ZLEN = N + N / 16 + 1;   // lpad(N) + the slot of the Nyquist column
+    const int tid = threadIdx.x, tl = tid % T, fl = tid / T;
+    float2* Z = reinterpret_cast<float2*>(smem) + (size_t)fl * ZLEN;
+    const GroupDev G = a.groups[g];
+    for (int fg = blockIdx.x; fg * F < n_frames_here; fg += gridDim.x) {
+        const bool live = fg * F + fl < n_frames_here;
+        const int gframe = frame0 + (live ? fg * F + fl : n_frames_here - 1);   // a padding frame repeats the last one and stores nothing
+        const float* pcm = a.pcm;
+        long long n_lead = a.n_lead, n_samples = a.n_samples, frame = gframe, out_row = gframe;
+        if (a.streams) {
+            int lo = 0, n = a.n_streams;   // the last stream whose first frame is at or before gframe
+            while (n > 1) {
+                const int h = n >> 1;
+                if (a.streams[lo + h].frame0 <= gframe) { lo += h; n -= h; } else n = h;
+            }
+            const FftStream st = a.streams[lo];
+            pcm = st.pcm;
+            n_lead = st.n_lead;
+            n_samples = st.n_samples;
+            frame = gframe - st.frame0;
+            out_row = st.row0 + frame;
+        }
+        const long long s0 = n_lead + (frame + 1) * a.hop - a.n_fft + G.w0;
+        // gather the window: Z[n] = (x[w0 + 2n], x[w0 + 2n + 1]), 16 points per thread, all loads in flight before the first LDS store
+        {
+            struct __attribute__((packed, aligned(4))) F2U { float x, y; };
+            float2 v[16];
+            if (s0 >= 0 && s0 + 2 * N <= n_samples) {   // the window lies inside the stream (all but a stream's first frames)
+                const F2U* src = reinterpret_cast<const F2U*>(pcm + s0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const F2U t = src[tl + u * T];
+                    v[u] = make_float2(t.x, t.y);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const long long sx = s0 + 2 * (tl + u * T);
+                    v[u] = make_float2(0.0f, 0.0f);
+                    if (sx >= 0 && sx < n_samples) v[u].x = pcm[sx];
+                    if (sx + 1 >= 0 && sx + 1 < n_samples) v[u].y = pcm[sx + 1];
+                }
+            }
+            float2* zt = Z + lpad(tl);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) zt[u * (T + T / 16)] = v[u];   // lpad(tl + u T) = lpad(tl) + u (T + T / 16): T is a multiple of 16
+        }
+        __syncthreads();
+        {
+            // (the thread's index goes through an empty asm once per frame: left to itself the compiler hoists the 15 twiddle ADDRESSES of every
+            // pass — loop-invariant 64-bit values — out of the frame loop and spills them: 380 bytes of scratch per lane, reloaded in every pass)
+            int tl_ = tl;
+            asm volatile("" : "+v"(tl_));
+            lds_fft_ct<N, 1, T>(Z, a.tw, a.n_tw, tl_, G.n_cols - 1);
+        }
+        // real split, in place, only for the columns the kernel reads (as in vqt_fft_frames)
+        for (int c = tl; c <= N / 2; c += T) {
+            const int d = N - c;
+            const bool need_c = c < G.n_cols, need_d = d < G.n_cols && d != c;
+            if (!need_c && !need_d) continue;
+            const float2 zc = Z[lpad(c & (N - 1))], zd = Z[lpad(d & (N - 1))];
+            auto column = [&](float2 za, float2 zb, int col) {   // za = Z[col], zb = conj(Z[N - col])
+                zb.y = -zb.y;
+                const float2 w = a.split_tw[G.split_off + col];
+                const float2 ev = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
+                const float2 dv = make_float2(0.5f * (za.x - zb.x), 0.5f * (za.y - zb.y));
+                const float2 t = cmul(w, dv);
+                return make_float2(ev.x + t.y, ev.y - t.x);
+            };
+            float2 sc = make_float2(0.0f, 0.0f), sd = sc;
+            if (need_c) sc = column(zc, zd, c);
+            if (need_d) sd = column(zd, zc, d);
+            if (need_c) Z[lpad(c)] = sc;
+            if (need_d) Z[lpad(d)] = sd;
+        }
+        __syncthreads();
+        // banded complex row dots: a team of G.tpr lanes walks one kernel row, every entry fetched once and applied to the F frames' spectra;
+        // the sums go straight to the frames' rows of x_vqt (xv_split)
+        {
+            const int tpr = G.tpr;
+            const int team = tid / tpr, tm = tid & (tpr - 1), n_teams = BLOCK / tpr;
+            const uint32_t* rp = a.row_ptr + G.row_ptr_off;
+            const float2* Z0 = reinterpret_cast<const float2*>(smem);
+            for (int row = team; row < G.n_rows; row += n_teams) {
+                const int s = G.ent_off + rp[row], e = G.ent_off + rp[row + 1];
+                float2 acc[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] = make_float2(0.0f, 0.0f);
+                for (int i = s + tm; i < e; i += tpr) {
+                    const float4 en = a.ent[i];
+                    const uint32_t c = __builtin_bit_cast(uint32_t, en.z);
+                    const int idx = lpad(c & 0x7fffu);
+                    const float sg = (c & 0x8000u) ? -1.0f : 1.0f;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        float2 x = Z0[(size_t)f * ZLEN + idx];
+                        x.y *= sg;
+                        acc[f].x = fmaf(-en.y, x.y, fmaf(en.x, x.x, acc[f].x));
+                        acc[f].y = fmaf(en.y, x.x, fmaf(en.x, x.y, acc[f].y));
+                    }
+                }
+                for (int o = tpr >> 1; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        acc[f].x += __shfl_xor(acc[f].x, o);
+                        acc[f].y += __shfl_xor(acc[f].y, o);
+                    }
+                }
+                if (tm == 0) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const int fr = fg * F + f;
+                        if (fr < n_frames_here) a.xv_split[(size_t)fr * a.n_bins + G.first_bin + row] = acc[f];   // (rows of the launch's frames, from frame0 on)
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the next frames' gather overwrites the spectrum columns
+    }
+}
+
 // the frames of a group-split launch: x_vqt rows -> (optional complex output), frame-relative dB; T threads per row as in the walk
 template <int T>
 __global__ __launch_bounds__(T) void db_rows(const float2* __restrict__ xv_rows, int n_rows, int n_bins, float* __restrict__ out_db, float2* __restrict__ out_cplx,
@@ -521,6 +771,29 @@ __global__ __launch_bounds__(T) void db_rows(const float2* __restrict__ xv_rows,
     if (out_cplx)
         for (int k = tid; k < n_bins; k += T) out_cplx[(size_t)row * n_bins + k] = xv[k];
     db_epilogue<T>(xv, red, n_bins, out_db + (size_t)row * n_bins, nullptr, tid, status, true);
+}
+
+// ... and of a vqt_fft_group launch: row r holds frame frame0 + r of the call, whose output row is the frame's own (one stream) or its stream's
+template <int T>
+__global__ __launch_bounds__(T) void db_rows_batch(const float2* __restrict__ xv_rows, int n_rows, int frame0, int n_bins, const FftStream* __restrict__ streams, int n_streams,
+                                                   float* __restrict__ out_db, float2* __restrict__ out_cplx, unsigned* status) {
+    __shared__ float red[2 * (T / 64)];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r >= n_rows) return;
+    long long out_row = frame0 + r;
+    if (streams) {
+        const int gframe = frame0 + r;
+        int lo = 0, n = n_streams;
+        while (n > 1) {
+            const int h = n >> 1;
+            if (streams[lo + h].frame0 <= gframe) { lo += h; n -= h; } else n = h;
+        }
+        out_row = streams[lo].row0 + (gframe - streams[lo].frame0);
+    }
+    const float2* xv = xv_rows + (size_t)r * n_bins;
+    if (out_cplx)
+        for (int k = tid; k < n_bins; k += T) out_cplx[(size_t)out_row * n_bins + k] = xv[k];
+    db_epilogue<T>(xv, red, n_bins, out_db + (size_t)out_row * n_bins, nullptr, tid, status, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -992,6 +1265,62 @@ pvq_status Vqt::launch_fft_streams(const void* st_table, size_t n_st, const floa
     static const int split_max_env = dev_knob("PVQ_FFT_SPLIT_MAX", 1500);
     const bool split = !st_table && split_env && a.n_groups > 1 && (size_t)grid * (size_t)a.n_groups <= (size_t)split_max_env;
     a.xv_split = nullptr;
+    // batches: one kernel instantiation per window size (vqt_fft_group), a launch per window group and 16 384-frame part, db_rows_batch
+    // behind them.  Same bits as the walk.  (developer build: PVQ_FFT_CT=0 keeps the walk)
+    static const int ct_env = dev_knob("PVQ_FFT_CT", 1);
+    bool ct = ct_env && !split && !skip_env && a.n_groups >= 1 && n_frames >= 64;
+    for (int g = 0; g < a.n_groups && ct; ++g) {
+        const int N = dev_->h_groups[g].n_cplx;
+        ct = N >= 256 && N <= 16384 && (N & (N - 1)) == 0;
+    }
+    if (ct) {
+        constexpr size_t PART = 16384;
+        pvq_status es = ensure_workspace(&ws_split_, &ws_split_cap_, std::min(PART, n_frames) * (size_t)a.n_bins * sizeof(float2));
+        if (es != PVQ_OK) return es;
+        a.xv_split = static_cast<float2*>(ws_split_);
+        slot_begin(SLOT_FFT_FRAMES, stream);
+        auto launch_group = [&](auto n_c, auto block_c, int g, int f0, int nf) -> pvq_status {
+            constexpr int N = decltype(n_c)::value, BLK = decltype(block_c)::value;
+            constexpr int Tg = N / 16, Fg = BLK / Tg;
+            const size_t lds_g = (size_t)Fg * (N + N / 16 + 1) * sizeof(float2);
+            auto kern = vqt_fft_group<N, BLK>;
+            PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+            const int grid_g = (int)std::min<size_t>(((size_t)nf + Fg - 1) / Fg, 4096);
+            hipLaunchKernelGGL(kern, dim3(grid_g), dim3(BLK), lds_g, stream, a, g, f0, nf);
+            return PVQ_OK;
+        };
+        using std::integral_constant;
+        for (size_t f0 = 0; f0 < n_frames; f0 += PART) {
+            const int nf = (int)std::min(PART, n_frames - f0);
+            for (int g = 0; g < a.n_groups; ++g) {
+                pvq_status ls = PVQ_OK;
+                switch (dev_->h_groups[g].n_cplx) {
+                    case 16384: ls = launch_group(integral_constant<int, 16384>{}, integral_constant<int, 1024>{}, g, (int)f0, nf); break;
+                    case 8192: ls = launch_group(integral_constant<int, 8192>{}, integral_constant<int, 512>{}, g, (int)f0, nf); break;
+                    case 4096: ls = launch_group(integral_constant<int, 4096>{}, integral_constant<int, 512>{}, g, (int)f0, nf); break;
+                    case 2048: ls = launch_group(integral_constant<int, 2048>{}, integral_constant<int, 512>{}, g, (int)f0, nf); break;
+                    case 1024: ls = launch_group(integral_constant<int, 1024>{}, integral_constant<int, 512>{}, g, (int)f0, nf); break;
+                    case 512: ls = launch_group(integral_constant<int, 512>{}, integral_constant<int, 256>{}, g, (int)f0, nf); break;
+                    default: ls = launch_group(integral_constant<int, 256>{}, integral_constant<int, 128>{}, g, (int)f0, nf); break;
+                }
+                if (ls != PVQ_OK) return ls;
+            }
+            hipLaunchKernelGGL(db_rows_batch<256>, dim3((unsigned)nf), dim3(256), 0, stream, static_cast<const float2*>(ws_split_), nf, (int)f0, a.n_bins, a.streams, a.n_streams,
+                               a.out_db, a.out_cplx, a.status);
+        }
+        slot_end(SLOT_FFT_FRAMES, stream);
+        if (pk) {
+            slot_begin(SLOT_PEAKS, stream);
+            pvq_status ps = launch_peaks_kernel(d_out_db, rows_total, *pk, stream);
+            slot_end(SLOT_PEAKS, stream);
+            if (ps != PVQ_OK) return ps;
+        }
+        PVQ_HIP(hipGetLastError());
+        last_algo_ = PVQ_ALGO_FFT;
+        last_frames_per_launch_ = (uint32_t)n_frames;
+        last_gemm_flop_ = 0.0;
+        return PVQ_OK;
+    }
     if (split) {
         pvq_status es = ensure_workspace(&ws_split_, &ws_split_cap_, n_frames * (size_t)a.n_bins * sizeof(float2));
         if (es != PVQ_OK) return es;

@@ -355,6 +355,50 @@ def test_tile_shapes_bit_identical_in_subprocesses():
             assert np.array_equal(a.view(np.uint32), res[tag][k].view(np.uint32)), (tag, k)
 
 
+def test_fft_batch_kernels_equal_the_walk_in_subprocesses():
+    """The FFT path's batch form (vqt_fft_group: one kernel instantiation per window size, round 5) against the walk (vqt_fft_frames, which the
+    developer library keeps for batches too with PVQ_FFT_CT=0): the same bits on every test geometry, at a power-of-two hop and at an odd one
+    (735 = pitchvis_serial's cadence at 22 050 Hz), stream start included.  Both forms share every arithmetic helper and vqt_engine.hip
+    compiles with FMA contraction off (fused multiply-adds are written where wanted), so this holds by construction; the test keeps it so.
+    (tests/test_parity_gpu.py::test_few_frames_on_the_fft_path_equal_the_same_frames_of_a_batch compares the few-frames forms of the walk with
+    the batch form in one process.)"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, os
+        sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+        import numpy as np, torch
+        import pitchvis_amd as P
+        from helpers import GEOMS, get_geom, white_noise
+        out = {}
+        for name in GEOMS:
+            pp, op = get_geom(name)
+            for hop in ((128 if op.sr > 90000 else 256), 735):
+                v = P.Vqt.new(pp, 0)
+                v.set_algo(P.ALGO_FFT)
+                nf, n_lead = 2500, 0 if hop == 735 else 4321
+                pcm = torch.from_numpy(white_noise(n_lead + hop * nf, 17)).cuda()
+                cx = torch.zeros((nf, v.n_bins, 2), device="cuda")
+                db = torch.empty((nf, v.n_bins), device="cuda")
+                v.calculate_batch_db_device(pcm, hop, nf, db, n_lead=n_lead, d_out_cplx=cx)
+                torch.cuda.synchronize()
+                out[f"{name}_{hop}_db"] = db.cpu().numpy()
+                out[f"{name}_{hop}_cx"] = cx.cpu().numpy()
+        np.savez(sys.argv[1], **out)
+        print("FFT_OK")
+    """)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    res = {}
+    for tag, env in (("batch", {}), ("walk", {"PVQ_DEV_LIB": "1", "PVQ_FFT_CT": "0"})):
+        f = os.path.join(root, "gpurun_out", f"fftforms_{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0 and "FFT_OK" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(f))
+        os.remove(f)
+    for k, a in res["batch"].items():
+        assert np.array_equal(a.view(np.uint32), res["walk"][k].view(np.uint32)), k
+
+
 @pytest.mark.parametrize("name", ["default_22k_588", "bench_48k_252", "bench_48k_288", "hires_96k_360", "hires_96k_840", "serial_22k_180"])
 def test_same_input_same_output_every_geometry(name):
     """Reference convention: same input => same output.  Three runs of the whole path per geometry and
