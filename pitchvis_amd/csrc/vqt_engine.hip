@@ -1480,14 +1480,25 @@ size_t Vqt::auto_block_min_frames(size_t hop, size_t r) const {
     // (a power-of-two hop: both paths' launches are short; the block path's two kernels cost 58-67 us up to ~1 000 frames at 48 kHz /
     // 252 bins, the FFT path — group-split for few frames, launch_fft_streams — 19 us for one frame, 42 for 256, 56 for 400)
     if (divides) return std::max<size_t>(64 * r, 384);
-    double t_fft = 3.0e-7 * fft_work;                                                     // us per frame, FFT path at scale
-    if (plan_.params.n_fft > 0 && fft_work > 6.0e5) t_fft *= 1.35;                        // (a 32 768-sample window: 1 024 threads per frame, one workgroup per CU)
+    // Both paths' time for n frames, in us, as measured on one box (profiles/r05_auto_rule.txt):
+    //   FFT path     t_fft (n + 500): the per-window kernels (round 5: half the walk's time) ~ the FFT work + the row dots (bins)
+    //   block path   max(floor, floor / 2 + t_block n): a launch pair cannot end before `floor` however few frames it holds; per frame the K loops'
+    //                depth x columns + the kernel product (bins)
+    // and the switch sits at the first n (in steps of 64 r) where the block path is the faster one.  At the reference's default geometry
+    // (22 050 Hz, 588 bins) the per-window FFT kernels run level with the general-hop block path — 0.035 against 0.038 us per frame at hop 1 600 —
+    // and AUTO stays on the FFT path at every size.
+    double t_fft = 1.45e-7 * fft_work + 1.0e-5 * (double)n_bins();
+    if (plan_.params.n_fft > 0 && fft_work > 6.0e5) t_fft *= 1.15;                        // (a 32 768-sample window: 1 024 threads per frame, one workgroup per CU)
     const double floor_block = 58.0 + 0.075 * ((double)hop_eff - 256.0) + 18.0;           // us: shortest launch pair of the general-hop kernels
-    const double t_block = (1.2e-5 * (double)hop_eff + 0.0015) * ((double)cols / 871.0);  // us per frame (871: the bound at 48 kHz / 252 bins, 602 of them read)
-    if (t_fft <= t_block) return 64 * r;   // (does not happen for hops the path takes: <= 4 096 samples)
-    const double n = floor_block / (t_fft - t_block);
+    const double t_block = 1.0e-5 * (double)hop_eff * ((double)cols / 871.0) + 3.2e-5 * (double)n_bins();   // (871: the column bound at 48 kHz / 252 bins, 602 of them read)
     const size_t lo = 64 * r;
-    return n < (double)lo ? lo : (size_t)n;
+    if (t_fft <= t_block) {   // the lines never cross beyond the floor: the switch, if any, lies where the FFT path reaches the block path's floor
+        const double n = floor_block / t_fft - 500.0;
+        return n > 0.0 && floor_block / 2 + t_block * n <= floor_block ? std::max(lo, (size_t)n) : ~(size_t)0 >> 1;
+    }
+    for (size_t n = lo; n < ((size_t)1 << 22); n += lo)
+        if (std::max(floor_block, floor_block / 2 + t_block * (double)n) < t_fft * ((double)n + 500.0)) return n;
+    return ~(size_t)0 >> 1;
 }
 
 size_t Vqt::blockdft_hop_factor(size_t hop) const {
