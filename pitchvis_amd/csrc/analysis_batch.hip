@@ -62,6 +62,8 @@ struct AbArgs {
     // calmness.rs:40: the peaks of the RAW frames depend on the input alone, not on the recurrence: found for all frames of all streams at
     // once by the frame kernels before this kernel starts (launch_peaks_frames), [stream][frame][words] bit masks
     const uint32_t* raw_mask;
+    float* sm_rows;     // [stream][frame][bin]: the smoothed frames (ab_recurrence -> ab_frames): the caller's x_vqt_smoothed, or a workspace of the object
+    float* tuning_in;   // [stream][frame]: 100 x the frame's power-weighted average deviation (ab_frames -> ab_tuning)
 };
 
 namespace {
@@ -86,81 +88,57 @@ __device__ __forceinline__ void ab_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// the same for LDS traffic only: the wave's LDS writes have landed (vector-memory loads — a frame's prefetches — stay in flight)
+__device__ __forceinline__ void ab_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ float ab_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 }  // namespace
 
-// LDS of one wave: the smoothed frame's row with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into
-// them), a scratch row (the amplitude weights of the flagged bins, then the per-bin peak indices of the pitch rows), the frame's
-// continuous peaks and their accuracy / deviation (npad / 2 each), flags, the compacted list of flagged bins, the raw frame's peak
-// mask words, the peak routines' scratch and the lean routine's peak list
+// ------------------------------------------------------------------------------------------------
+// Round 5: the frame loop is split by what actually recurs.  Of preprocess's steps only three carry state from frame to frame:
+// the per-bin EMA (its horizon follows the scene calmness of the frame before: analysis.rs:295-323), the afterglow (afterglow.rs:27-36)
+// and the calmness step (calmness.rs:23-95: per-bin calmness / released EMAs, the scene calmness) — and none of them looks at the
+// smoothed frame's PEAKS: the calmness step takes the raw frame's peaks (found before, frame-parallel: raw_mask) and the smoothed
+// values.  find_peaks on the smoothed frame, enhance_peaks_continuous, promote_bass_peaks_with_harmonics, the peak-filtered frame, the
+// pitch accuracy / deviation rows and the frame's power-weighted tuning inaccuracy depend on that frame's smoothed row alone.  So:
+//   ab_recurrence   one wave per STREAM walks the frames in order: EMA -> smoothed row (kept: it is an output, or a workspace),
+//                   afterglow, calmness, scene calmness.  ~300 instructions per frame instead of ~1 500 (2 700 at 588 bins).
+//   ab_frames       one wave per (stream, FRAME), every frame of every stream at once: the smoothed row's peaks and everything
+//                   derived from them; leaves the frame's tuning-grid inaccuracy (100 x average) for
+//   ab_tuning       one thread per stream: the scalar EMA of pitch_analysis.rs:55-66 over the call's frames.
+// Same operations in the same order as the single kernel of rounds 3-4 (and as the host AnalysisState): the recurrence state stays
+// bit-identical to the oracle (tests/test_analysis_batch_gpu.py).  64 streams no longer mean 64 busy waves for the whole call.
+// ------------------------------------------------------------------------------------------------
+// LDS of one wave of ab_recurrence: the smoothed frame's row, the amplitude weights of the flagged bins, the compacted list of
+// flagged bins, the raw frame's peak mask words
+__host__ __device__ inline unsigned ab_rec_wave_bytes(int n_bins) {
+    const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
+    return (unsigned)((sizeof(float) * 2 * npad + 2 * npad + 4 * 32 + 15) / 16 * 16);
+}
+// ... of ab_frames: the smoothed row with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into them), a
+// scratch row (the pitch rows' peak indices), the frame's continuous peaks and their accuracy / deviation (npad / 2 each), flags, the
+// compacted bass list, the peak routines' scratch and the lean routine's peak list
 __host__ __device__ inline unsigned ab_wave_bytes(int n_bins, unsigned scratch_bytes) {
     const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
-    return (unsigned)((sizeof(float) * ((npad + 2 * PK_PAD) + npad + 4 * (npad / 2)) + npad /*flags*/ + 2 * npad /*flagged bins: npad u16*/ + 4 * 32 /*mask words*/ +
+    return (unsigned)((sizeof(float) * ((npad + 2 * PK_PAD) + npad + 4 * (npad / 2)) + npad /*flags*/ + 2 * npad /*bass list: u16*/ +
                        scratch_bytes + npad /*lean peak list: npad / 2 u16*/ + 15) / 16 * 16);
 }
 
-template <int NK, bool DIST, int OCC>   // OCC: waves per SIMD the register budget is cut for (4 waves per workgroup: OCC workgroups per CU)
-__global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) {
+template <int NK>
+__global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recurrence(AbArgs a) {   // (the per-bin state lives in registers: 7 NK values per lane)
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x * 4 + wave;
     const int n = a.n_bins, npad = (n + 63) / 64 * 64, words = (n + 31) / 32;
-    const float INF = __builtin_huge_valf();
-
-    PeakParamsDev ps{};   // analysis.rs:332-349: bass config at or below highest_bassnote, general config above
-    ps.n_bins = n; ps.bpo = a.bpo; ps.min_freq = a.min_freq; ps.lnf = a.lnf;
-    ps.peak_min_prominence = a.peak_prom; ps.peak_min_height = a.peak_h;
-    ps.bass_min_prominence = a.bass_prom; ps.bass_min_height = a.bass_h;
-    ps.highest_bassnote = a.highest_bassnote; ps.harmonic_threshold = a.harm_thr;
-    ps.dist = a.dist; ps.min_bin = a.min_bin;
-    ps.mask = (a.o.peak_mask && s < a.n_streams) ? a.o.peak_mask + (size_t)s * a.n_frames * words : nullptr;
-    ps.count = (a.o.peak_count && s < a.n_streams) ? a.o.peak_count + (size_t)s * a.n_frames : nullptr;
-    ps.center = nullptr; ps.size = nullptr; ps.max_peaks = 0;
-
-    // workgroup-shared: the per-bin thresholds of the lean routine's candidate test (the bass / general split configuration)
-    float* thr = reinterpret_cast<float*>(ab_lds);   // [2][npad]: H, P
-    peaks_lean_thresholds(thr, thr + npad, ps, tid, 256);
-    __syncthreads();
-    if (s >= a.n_streams) return;   // (no workgroup barrier below: waves are independent)
-
-    unsigned char* base = ab_lds + (size_t)2 * npad * sizeof(float) + (size_t)wave * a.wave_bytes;
-    float* rowA = reinterpret_cast<float*>(base) + PK_PAD;      // the smoothed frame (find_peaks input), +INF on both sides
-    float* rowB = rowA + npad + PK_PAD;                         // scratch row: amplitude weights of the flagged bins, then the pitch rows' peak indices
-    float* pw = rowB;                                           // 10^(dB / 10) of the bins around a raw peak
-    float* pc_c = rowB + npad;                                  // peaks_continuous of the frame: center, size (npad / 2 each)
-    float* pc_s = pc_c + npad / 2;
-    float* pk_acc = pc_s + npad / 2;                            // ... and their pitch accuracy / deviation
-    float* pk_dev = pk_acc + npad / 2;
-    unsigned char* flag = reinterpret_cast<unsigned char*>(pk_dev + npad / 2);   // is-peak / around-a-raw-peak flags
-    uint16_t* flist = reinterpret_cast<uint16_t*>(flag + npad);                  // compacted lists: bass peaks, then flagged bins (room for npad)
-    uint32_t* mwords = reinterpret_cast<uint32_t*>(flist + npad);                // the raw frame's peak mask (32 words)
-    unsigned char* scratch = reinterpret_cast<unsigned char*>(mwords + 32);      // the peak routines' scratch
-    uint16_t* plist_lean = reinterpret_cast<uint16_t*>(scratch + a.scratch_bytes);
-    const uint16_t* plist_gen = reinterpret_cast<const uint16_t*>(scratch + npad);   // where peaks_wave_nk leaves its list
-    for (int i = lane; i < PK_PAD; i += 64) {   // sentinels (the frame's own tail up to npad follows below, once)
-        rowA[-PK_PAD + i] = INF;
-        rowA[npad + i] = INF;
-    }
-    for (int i = n + lane; i < npad; i += 64) rowA[i] = INF;
-
-    // find_peaks of one frame row: the lean routine, or — a plateau of three or more samples somewhere in the frame, or the
-    // developer switch — the generic one; returns where the peak list (ascending bins, u16) was left
-    auto find_peaks_row = [&](float* row, const float* tH, const float* tP, const PeakParamsDev& pp, int f, uint32_t& total) -> const uint16_t* {
-        uint32_t n_cand[1] = {0}, np[1] = {0};
-        bool done = false;
-        if (!a.generic_peaks) done = peaks_lean_scan<NK, DIST>(row, scratch, tH, tP, n_cand[0], pp, lane);
-        if (done) {
-            const bool wr[1] = {true};
-            const size_t fr_[1] = {(size_t)f};
-            peaks_lean_walk<NK, 1>(row, 0, scratch, 0, plist_lean, npad / 2, n_cand, np, wr, fr_, pp, lane);
-            total = np[0];
-            return plist_lean;
-        }
-        ab_wave_sync();
-        peaks_wave_nk<NK>(row, scratch, (size_t)f, pp, lane, &total);
-        return plist_gen;
-    };
+    if (s >= a.n_streams) return;   // (no workgroup barrier in this kernel: waves are independent)
+    unsigned char* base = ab_lds + (size_t)wave * ab_rec_wave_bytes(n);
+    float* rowA = reinterpret_cast<float*>(base);                 // the smoothed frame
+    float* pw = rowA + npad;                                      // 10^(dB / 10) of the bins around a raw peak
+    uint16_t* flist = reinterpret_cast<uint16_t*>(pw + npad);     // compacted list of the flagged bins
+    uint32_t* mwords = reinterpret_cast<uint32_t*>(flist + npad); // the raw frame's peak mask (32 words)
 
     float y_sm[NK], y_calm[NK], y_rel[NK], y_glow[NK];
     float bm[NK], glow_k[NK];   // analysis.rs:310-316 base * frequency_multiplier; afterglow.rs:31 decay per bin
@@ -178,15 +156,22 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
         bm[k] = (float)a.base_ms * frequency_multiplier;
         glow_k[k] = 0.85f - 0.15f * ((float)bin / n_f);
     }
-    float scene = a.scene[s], tuning = a.tuning[s];
-    const float note_s = ab_secs(a.note_ns), scene_s = ab_secs(a.scene_ns), tuning_s = ab_secs(a.tuning_ns);
-    const bool last_call_frame_state = true;   // peak-filtered frame, pitch accuracy / deviation of the call's LAST frame are part of the state (the getters)
+    float scene = a.scene[s];
+    const float note_s = ab_secs(a.note_ns), scene_s = ab_secs(a.scene_ns);
     const float* db_s = a.db + (size_t)s * a.n_frames * n;
-    float xn[NK];   // the next frame's values, fetched a frame ahead
+    float* sm_s = a.sm_rows + (size_t)s * a.n_frames * n;   // the smoothed rows: the caller's x_vqt_smoothed, or the object's workspace
+    // The next frame's values and raw-peak mask word are fetched a frame ahead, and a frame's EMA weights all at once — with UNCONDITIONAL loads
+    // (clamped addresses, the lanes past the frame's end select afterwards): behind a per-lane `if` the compiler waits for every load right
+    // where it issues it (s_waitcnt vmcnt(0) inside the branch), and the wave stood through 2 NK global-memory round trips per frame.
+    int binc[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) xn[k] = (lane + 64 * k < n && a.n_frames > 0) ? db_s[lane + 64 * k] : 0.0f;
+    for (int k = 0; k < NK; ++k) binc[k] = min(lane + 64 * k, n - 1);
+    float xn[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) xn[k] = db_s[binc[k]];
     const uint32_t* rm_s = a.raw_mask + (size_t)s * a.n_frames * words;
-    uint32_t mw_next = (lane < words && a.n_frames > 0) ? rm_s[lane] : 0u;   // ... and its raw-peak mask word (lane < words <= 32)
+    const int wlane = min(lane, words - 1);
+    uint32_t mw_next = rm_s[wlane];   // (lane < words <= 32 holds a word of the mask)
 
     for (int f = 0; f < a.n_frames; ++f) {
         const size_t fr = (size_t)s * a.n_frames + f;
@@ -195,35 +180,201 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
         const float* tab = a.alpha_tab ? a.alpha_tab + (size_t)(a.frame_row ? a.frame_row[f] : 0u) * a.tab_stride : nullptr;
         const float alpha_c = tab ? tab[0] : 1.0f - ab_exp(-2.0f * dt_s / note_s);
         const float alpha_s = tab ? tab[1] : 1.0f - ab_exp(-2.0f * dt_s / scene_s);
-        const float alpha_t = tab ? tab[2] : 1.0f - ab_exp(-2.0f * dt_s / tuning_s);
-        // ---- analysis.rs:295-323: per-bin EMA with a frequency- and calmness-dependent horizon
+        // ---- analysis.rs:295-323: per-bin EMA with a frequency- and calmness-dependent horizon; afterglow.rs:27-36
         const float cm = a.calm_min + (a.calm_max - a.calm_min) * scene;
-        float xr[NK];
+        float alpha[NK];
+        if (a.smooth_has) {   // (uniform)
+            unsigned long long hms[NK];
+            bool miss = false;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                hms[k] = a.base_ms > 0 ? ab_trunc_u64(bm[k] * cm) : 0ull;
+                miss |= !(tab && hms[k] < (unsigned long long)a.tab_n);
+            }
+            if (__ballot(miss) == 0) {   // the usual case: every weight is in the host's table — all NK loads in flight together
+#pragma unroll
+                for (int k = 0; k < NK; ++k) alpha[k] = tab[4 + (int)hms[k]];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    if (tab && hms[k] < (unsigned long long)a.tab_n) alpha[k] = tab[4 + (int)hms[k]];
+                    else alpha[k] = 1.0f - ab_exp(-2.0f * dt_s / ab_secs(hms[k] * 1000000ull));
+                }
+            }
+        }
+        // the next frame's inputs (the last frame fetches itself again), issued BEHIND the weights' loads: vector-memory loads return in order,
+        // so the wait for the weights leaves these in flight for the whole frame
+        const size_t fnext = (size_t)(f + 1 < a.n_frames ? f + 1 : f);
+        float xnext[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xnext[k] = db_s[fnext * n + binc[k]];
+        const uint32_t mw_after = rm_s[fnext * words + wlane];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
-            xr[k] = xn[k];
+            const float x = xn[k];
+            if (!a.smooth_has) y_sm[k] = x;   // util.rs:117-120
+            else y_sm[k] = y_sm[k] + alpha[k] * (x - y_sm[k]);
+            float g = y_glow[k];
+            g *= glow_k[k];
+            if (g < y_sm[k]) g = y_sm[k];
+            y_glow[k] = g;
             if (bin < n) {
-                const float x = xr[k];
-                if (f + 1 < a.n_frames) xn[k] = db_s[(size_t)(f + 1) * n + bin];
-                if (!a.smooth_has) {
-                    y_sm[k] = x;   // util.rs:117-120
-                } else {
-                    const unsigned long long hms = a.base_ms > 0 ? ab_trunc_u64(bm[k] * cm) : 0ull;
-                    float alpha;
-                    if (tab && hms < (unsigned long long)a.tab_n) alpha = tab[4 + (int)hms];
-                    else alpha = 1.0f - ab_exp(-2.0f * dt_s / ab_secs(hms * 1000000ull));
-                    y_sm[k] = y_sm[k] + alpha * (x - y_sm[k]);
-                }
                 rowA[bin] = y_sm[k];
+                sm_s[(size_t)f * n + bin] = y_sm[k];
+                if (a.o.x_vqt_afterglow) a.o.x_vqt_afterglow[fr * n + bin] = g;
             }
         }
         if (lane < 32) mwords[lane] = mw_next;
-        if (lane < words && f + 1 < a.n_frames) mw_next = rm_s[(size_t)(f + 1) * words + lane];
+        ab_lds_sync();
+        // ---- calmness.rs:23-95: the peaks of the RAW frame (found before this kernel started: raw_mask) mark the bins "around a note":
+        //      peak p flags [max(0, p - radius), min(n, p + radius)), i.e. bin i is flagged iff one of the bins i - radius + 1 ... i + radius is a peak
+        auto raw_peak = [&](int p) { return p >= 0 && p < n && ((mwords[p >> 5] >> (p & 31)) & 1u) != 0; };
+        // amplitude weights 10^(dB / 10) of the flagged bins only (a handful per frame): compacted, one lane per flagged bin
+        bool fl[NK];
+        {
+            uint32_t n_fl = 0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int bin = lane + 64 * k;
+                bool any = false;
+                for (int p = bin - a.radius + 1; p <= bin + a.radius; ++p) any |= raw_peak(p);
+                fl[k] = bin < n && any;
+                const unsigned long long bmk = __ballot(fl[k]);
+                if (fl[k]) flist[n_fl + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)bin;
+                n_fl += __popcll(bmk);
+            }
+            ab_lds_sync();
+            for (uint32_t idx = lane; idx < n_fl; idx += 64) {
+                const int bin = flist[idx];
+                pw[bin] = ab_pow10(rowA[bin] / 10.0f);
+            }
+            ab_lds_sync();
+        }
+        {
+            float weighted_sum = 0.0f, weight_sum = 0.0f;   // in bin order, as the reference's loop; bins that contribute nothing are skipped
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int bin = lane + 64 * k;
+                float ws = 0.0f, w = 0.0f;
+                if (bin < n) {
+                    if (fl[k]) {
+                        y_calm[k] = y_calm[k] + alpha_c * (1.0f - y_calm[k]);
+                        y_rel[k] = y_calm[k];
+                        const float power = pw[bin];
+                        ws = y_calm[k] * power;
+                        w = power;
+                    } else {
+                        y_calm[k] = y_calm[k] + alpha_c * (0.0f - y_calm[k]);
+                        y_rel[k] = y_rel[k] + alpha_c * (0.0f - y_rel[k]);
+                        if (y_rel[k] > 0.01f) {
+                            w = y_rel[k] * 0.3f;
+                            ws = y_rel[k] * w;
+                        }
+                    }
+                    if (a.o.calmness) a.o.calmness[fr * n + bin] = y_calm[k];
+                }
+                unsigned long long m = __ballot(ws != 0.0f || w != 0.0f);   // (adding +0.0 to a non-negative sum changes nothing)
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    weighted_sum += ab_readlane(ws, b);
+                    weight_sum += ab_readlane(w, b);
+                }
+            }
+            if (weight_sum > 0.0f) scene = scene + alpha_s * (weighted_sum / weight_sum - scene);
+        }
+        if (lane == 0 && a.o.scene_calmness) a.o.scene_calmness[fr] = scene;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xn[k] = xnext[k];
+        mw_next = mw_after;
+        ab_lds_sync();
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int bin = lane + 64 * k;
+        if (bin < n) {
+            a.smoothed[(size_t)s * n + bin] = y_sm[k];
+            a.calm[(size_t)s * n + bin] = y_calm[k];
+            a.released[(size_t)s * n + bin] = y_rel[k];
+            a.afterglow[(size_t)s * n + bin] = y_glow[k];
+        }
+    }
+    if (lane == 0) a.scene[s] = scene;
+}
+
+template <int NK, bool DIST>
+__global__ __launch_bounds__(256, 2) void ab_frames(AbArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n_bins, npad = (n + 63) / 64 * 64, words = (n + 31) / 32;
+    const float INF = __builtin_huge_valf();
+    const long long rows = (long long)a.n_streams * a.n_frames;
+
+    PeakParamsDev ps{};   // analysis.rs:332-349: bass config at or below highest_bassnote, general config above
+    ps.n_bins = n; ps.bpo = a.bpo; ps.min_freq = a.min_freq; ps.lnf = a.lnf;
+    ps.peak_min_prominence = a.peak_prom; ps.peak_min_height = a.peak_h;
+    ps.bass_min_prominence = a.bass_prom; ps.bass_min_height = a.bass_h;
+    ps.highest_bassnote = a.highest_bassnote; ps.harmonic_threshold = a.harm_thr;
+    ps.dist = a.dist; ps.min_bin = a.min_bin;
+    ps.mask = a.o.peak_mask;     // [stream][frame][words] = [row][words]
+    ps.count = a.o.peak_count;
+    ps.center = nullptr; ps.size = nullptr; ps.max_peaks = 0;
+
+    // workgroup-shared: the per-bin thresholds of the lean routine's candidate test (the bass / general split configuration)
+    float* thr = reinterpret_cast<float*>(ab_lds);   // [2][npad]: H, P
+    peaks_lean_thresholds(thr, thr + npad, ps, tid, 256);
+    __syncthreads();
+
+    unsigned char* base = ab_lds + (size_t)2 * npad * sizeof(float) + (size_t)wave * a.wave_bytes;
+    float* rowA = reinterpret_cast<float*>(base) + PK_PAD;      // the smoothed frame (find_peaks input), +INF on both sides
+    float* rowB = rowA + npad + PK_PAD;                         // scratch row: the pitch rows' peak indices
+    float* pc_c = rowB + npad;                                  // peaks_continuous of the frame: center, size (npad / 2 each)
+    float* pc_s = pc_c + npad / 2;
+    float* pk_acc = pc_s + npad / 2;                            // ... and their pitch accuracy / deviation
+    float* pk_dev = pk_acc + npad / 2;
+    unsigned char* flag = reinterpret_cast<unsigned char*>(pk_dev + npad / 2);   // is-peak flags
+    uint16_t* flist = reinterpret_cast<uint16_t*>(flag + npad);                  // compacted list of the bass peaks
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(flist + npad);     // the peak routines' scratch
+    uint16_t* plist_lean = reinterpret_cast<uint16_t*>(scratch + a.scratch_bytes);
+    const uint16_t* plist_gen = reinterpret_cast<const uint16_t*>(scratch + npad);   // where peaks_wave_nk leaves its list
+    for (int i = lane; i < PK_PAD; i += 64) {
+        rowA[-PK_PAD + i] = INF;
+        rowA[npad + i] = INF;
+    }
+    for (int i = n + lane; i < npad; i += 64) rowA[i] = INF;
+    const float bpo_f = (float)a.bpo, n_f = (float)n;
+
+    for (long long fr = (long long)blockIdx.x * 4 + wave; fr < rows; fr += (long long)gridDim.x * 4) {
+        const int s = (int)(fr / a.n_frames), f = (int)(fr - (long long)s * a.n_frames);
+        float y_sm[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int bin = lane + 64 * k;
+            y_sm[k] = a.sm_rows[(size_t)fr * n + min(bin, n - 1)];   // (unconditional, clamped: all NK loads in flight together)
+            if (bin < n) rowA[bin] = y_sm[k];
+        }
         ab_wave_sync();
         // ---- analysis.rs:332-349: peaks of the smoothed frame (mask / count go straight to the outputs)
         uint32_t total = 0;
-        const uint16_t* plist = find_peaks_row(rowA, thr, thr + npad, ps, f, total);
+        const uint16_t* plist;
+        {
+            uint32_t n_cand[1] = {0}, np[1] = {0};
+            bool done = false;
+            if (!a.generic_peaks) done = peaks_lean_scan<NK, DIST>(rowA, scratch, thr, thr + npad, n_cand[0], ps, lane);
+            if (done) {
+                const bool wr[1] = {true};
+                const size_t fr_[1] = {(size_t)fr};
+                peaks_lean_walk<NK, 1>(rowA, 0, scratch, 0, plist_lean, npad / 2, n_cand, np, wr, fr_, ps, lane);
+                total = np[0];
+                plist = plist_lean;
+            } else {
+                ab_wave_sync();
+                peaks_wave_nk<NK>(rowA, scratch, (size_t)fr, ps, lane, &total);
+                plist = plist_gen;
+            }
+        }
         ab_wave_sync();
         // ---- peak_detection.rs:61-148: one lane per peak (ascending bins = ascending centres: a centre stays between its peak's
         //      neighbours and peaks are never adjacent)
@@ -265,7 +416,7 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
                 flag[p] = 1;
             }
             // promote_bass_peaks_with_harmonics applies to the peaks whose centre is not above highest_bassnote: their list
-            // positions go to the head of flist (free until the calmness step)
+            // positions go to flist
             const bool is_bass = have && !(ctr > (float)a.highest_bassnote);
             const unsigned long long bmk = __ballot(is_bass);
             if (is_bass) flist[n_bass + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)idx;
@@ -309,27 +460,21 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
         ab_wave_sync();
         if (a.o.center) {
             for (uint32_t idx = lane; idx < total && idx < a.o.max_peaks; idx += 64) {
-                a.o.center[fr * a.o.max_peaks + idx] = pc_c[idx];
-                a.o.size[fr * a.o.max_peaks + idx] = pc_s[idx];
+                a.o.center[(size_t)fr * a.o.max_peaks + idx] = pc_c[idx];
+                a.o.size[(size_t)fr * a.o.max_peaks + idx] = pc_s[idx];
             }
         }
-        // ---- afterglow.rs:27-36, :10-21
+        // ---- afterglow.rs:10-21: the peak-filtered frame
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
             if (bin < n) {
                 const float pf = flag[bin] ? y_sm[k] : 0.0f;
-                float g = y_glow[k];
-                g *= glow_k[k];
-                if (g < y_sm[k]) g = y_sm[k];
-                y_glow[k] = g;
-                if (a.o.x_vqt_smoothed) a.o.x_vqt_smoothed[fr * n + bin] = y_sm[k];
-                if (a.o.x_vqt_peakfiltered) a.o.x_vqt_peakfiltered[fr * n + bin] = pf;
-                if (a.o.x_vqt_afterglow) a.o.x_vqt_afterglow[fr * n + bin] = g;
-                if (last_call_frame_state && f == a.n_frames - 1) a.peakfiltered[(size_t)s * n + bin] = pf;
+                if (a.o.x_vqt_peakfiltered) a.o.x_vqt_peakfiltered[(size_t)fr * n + bin] = pf;
+                if (f == a.n_frames - 1) a.peakfiltered[(size_t)s * n + bin] = pf;   // (the call's last frame is part of the state: the getters)
             }
         }
-        // ---- pitch_analysis.rs:55-66: tuning-grid inaccuracy, power-weighted, accumulated in peak order;
+        // ---- pitch_analysis.rs:55-66: tuning-grid inaccuracy, power-weighted, accumulated in peak order (its EMA over the frames: ab_tuning);
         //      pitch_analysis.rs:12-42: per-bin accuracy / deviation at the peaks' nearest bins, later peaks overwrite earlier ones
         //      (centres ascend, so the peaks that round to one bin are neighbours in the list: the last of them writes)
         {
@@ -347,73 +492,15 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
                     power_sum += ab_readlane(power, (int)j);
                     inaccuracy_sum += ab_readlane(wi, (int)j);
                 }
-                if (have) {   // (the per-bin rows are put together after the calmness step, in the raw frame's row)
+                if (have) {
                     pk_acc[idx] = fmaxf(1.0f - 2.0f * fabsf(deviation), 0.0f);
                     pk_dev[idx] = deviation;
                 }
             }
             const float avg = power_sum > 0.0f ? inaccuracy_sum / power_sum : 0.0f;
-            tuning = tuning + alpha_t * (100.0f * avg - tuning);
+            if (lane == 0) a.tuning_in[fr] = 100.0f * avg;
         }
-        ab_wave_sync();
-        // ---- calmness.rs:23-95: the peaks of the RAW frame (found before this kernel started: raw_mask) mark the bins "around a note":
-        //      peak p flags [max(0, p - radius), min(n, p + radius)), i.e. bin i is flagged iff one of the bins i - radius + 1 ... i + radius is a peak
-        auto raw_peak = [&](int p) { return p >= 0 && p < n && ((mwords[p >> 5] >> (p & 31)) & 1u) != 0; };
-        // amplitude weights 10^(dB / 10) of the flagged bins only (a handful per frame): compacted, one lane per flagged bin
-        bool fl[NK];
-        {
-            uint32_t n_fl = 0;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int bin = lane + 64 * k;
-                bool any = false;
-                for (int p = bin - a.radius + 1; p <= bin + a.radius; ++p) any |= raw_peak(p);
-                fl[k] = bin < n && any;
-                const unsigned long long bmk = __ballot(fl[k]);
-                if (fl[k]) flist[n_fl + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)bin;
-                n_fl += __popcll(bmk);
-            }
-            ab_wave_sync();
-            for (uint32_t idx = lane; idx < n_fl; idx += 64) {
-                const int bin = flist[idx];
-                pw[bin] = ab_pow10(rowA[bin] / 10.0f);
-            }
-            ab_wave_sync();
-        }
-        {
-            float weighted_sum = 0.0f, weight_sum = 0.0f;   // in bin order, as the reference's loop; bins that contribute nothing are skipped
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int bin = lane + 64 * k;
-                float ws = 0.0f, w = 0.0f;
-                if (bin < n) {
-                    if (fl[k]) {
-                        y_calm[k] = y_calm[k] + alpha_c * (1.0f - y_calm[k]);
-                        y_rel[k] = y_calm[k];
-                        const float power = pw[bin];
-                        ws = y_calm[k] * power;
-                        w = power;
-                    } else {
-                        y_calm[k] = y_calm[k] + alpha_c * (0.0f - y_calm[k]);
-                        y_rel[k] = y_rel[k] + alpha_c * (0.0f - y_rel[k]);
-                        if (y_rel[k] > 0.01f) {
-                            w = y_rel[k] * 0.3f;
-                            ws = y_rel[k] * w;
-                        }
-                    }
-                    if (a.o.calmness) a.o.calmness[fr * n + bin] = y_calm[k];
-                }
-                unsigned long long m = __ballot(ws != 0.0f || w != 0.0f);   // (adding +0.0 to a non-negative sum changes nothing)
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    weighted_sum += ab_readlane(ws, b);
-                    weight_sum += ab_readlane(w, b);
-                }
-            }
-            if (weight_sum > 0.0f) scene = scene + alpha_s * (weighted_sum / weight_sum - scene);
-        }
-        // ---- pitch accuracy / deviation rows, in the raw frame's row (dead now): bin <- 1 + index of the peak that writes it
+        // ---- pitch accuracy / deviation rows: bin <- 1 + index of the peak that writes it
         ab_wave_sync();
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
@@ -432,34 +519,34 @@ __global__ __launch_bounds__(256, OCC) void analysis_batch_preprocess(AbArgs a) 
             if (bin < n) {
                 const int w = (int)rowB[bin];
                 const float acc = w ? pk_acc[w - 1] : 0.0f, dev = w ? pk_dev[w - 1] : 0.0f;
-                if (a.o.pitch_accuracy) a.o.pitch_accuracy[fr * n + bin] = acc;
-                if (a.o.pitch_deviation) a.o.pitch_deviation[fr * n + bin] = dev;
-                if (last_call_frame_state && f == a.n_frames - 1) {
+                if (a.o.pitch_accuracy) a.o.pitch_accuracy[(size_t)fr * n + bin] = acc;
+                if (a.o.pitch_deviation) a.o.pitch_deviation[(size_t)fr * n + bin] = dev;
+                if (f == a.n_frames - 1) {
                     a.pitch_acc[(size_t)s * n + bin] = acc;
                     a.pitch_dev[(size_t)s * n + bin] = dev;
                 }
             }
         }
-        if (lane == 0) {
-            if (a.o.scene_calmness) a.o.scene_calmness[fr] = scene;
-            if (a.o.tuning_grid_inaccuracy) a.o.tuning_grid_inaccuracy[fr] = tuning;
-        }
         ab_wave_sync();
     }
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int bin = lane + 64 * k;
-        if (bin < n) {
-            a.smoothed[(size_t)s * n + bin] = y_sm[k];
-            a.calm[(size_t)s * n + bin] = y_calm[k];
-            a.released[(size_t)s * n + bin] = y_rel[k];
-            a.afterglow[(size_t)s * n + bin] = y_glow[k];
-        }
+}
+
+// pitch_analysis.rs:55-66: smoothed_tuning_grid_inaccuracy, one thread per stream over the call's frames
+__global__ __launch_bounds__(256) void ab_tuning(AbArgs a) {
+#pragma clang fp contract(off)
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_streams) return;
+    float tuning = a.tuning[s];
+    const float tuning_s = ab_secs(a.tuning_ns);
+    for (int f = 0; f < a.n_frames; ++f) {
+        const size_t fr = (size_t)s * a.n_frames + f;
+        const unsigned long long dt_ns = a.frame_times ? a.frame_times[f] : a.frame_ns;
+        const float* tab = a.alpha_tab ? a.alpha_tab + (size_t)(a.frame_row ? a.frame_row[f] : 0u) * a.tab_stride : nullptr;
+        const float alpha_t = tab ? tab[2] : 1.0f - ab_exp(-2.0f * ab_secs(dt_ns) / tuning_s);
+        tuning = tuning + alpha_t * (a.tuning_in[fr] - tuning);
+        if (a.o.tuning_grid_inaccuracy) a.o.tuning_grid_inaccuracy[fr] = tuning;
     }
-    if (lane == 0) {
-        a.scene[s] = scene;
-        a.tuning[s] = tuning;
-    }
+    a.tuning[s] = tuning;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,9 +756,11 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     a.scratch_bytes = (unsigned)((std::max(peaks_scratch_bytes(a.n_bins, a.dist), peaks_lean_scratch_bytes(a.n_bins, a.dist)) + 15) / 16 * 16);
     a.wave_bytes = ab_wave_bytes(a.n_bins, a.scratch_bytes);
     a.generic_peaks = dev_knob("PVQ_AB_GENERIC", 0);
-    {   // the raw frames' peaks (calmness.rs:40: the general configuration on the whole frame), every frame of every stream at once
+    {   // the raw frames' peaks (calmness.rs:40: the general configuration on the whole frame), every frame of every stream at once;
+        // workspace of the call: the masks, the frames' tuning inputs, the smoothed rows unless the caller takes them, the frame kernels' redo flags
         const size_t rows = (size_t)n_streams_ * n_frames, words = (size_t)(a.n_bins + 31) / 32;
-        const size_t need = rows * words * sizeof(uint32_t) + rows;   // masks, then the frame kernels' redo flags
+        const size_t b_mask = rows * words * sizeof(uint32_t), b_tun = rows * sizeof(float), b_sm = outs.x_vqt_smoothed ? 0 : rows * (size_t)a.n_bins * sizeof(float);
+        const size_t need = b_mask + b_tun + b_sm + rows;
         if (raw_cap_ < need) {
             if (d_raw_) PVQ_HIP(hipFree(d_raw_));   // (synchronises the device: nothing still reads the old buffer)
             d_raw_ = nullptr;
@@ -679,46 +768,54 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
             PVQ_HIP(hipMalloc(&d_raw_, need));
             raw_cap_ = need;
         }
+        char* wsb = static_cast<char*>(d_raw_);
+        a.raw_mask = reinterpret_cast<const uint32_t*>(wsb);
+        a.tuning_in = reinterpret_cast<float*>(wsb + b_mask);
+        a.sm_rows = outs.x_vqt_smoothed ? outs.x_vqt_smoothed : reinterpret_cast<float*>(wsb + b_mask + b_tun);
         PeakParamsDev pg{};
         pg.n_bins = a.n_bins; pg.bpo = a.bpo; pg.min_freq = a.min_freq; pg.lnf = a.lnf;
         pg.peak_min_prominence = a.peak_prom; pg.peak_min_height = a.peak_h;
         pg.bass_min_prominence = a.peak_prom; pg.bass_min_height = a.peak_h;
         pg.highest_bassnote = a.highest_bassnote; pg.harmonic_threshold = a.harm_thr;
         pg.dist = a.dist; pg.min_bin = a.min_bin;
-        pg.mask = static_cast<uint32_t*>(d_raw_);
+        pg.mask = reinterpret_cast<uint32_t*>(wsb);
         pg.count = nullptr; pg.center = nullptr; pg.size = nullptr; pg.max_peaks = 0;
-        pvq_status ps = launch_peaks_frames(d_db, rows, pg, reinterpret_cast<uint8_t*>(static_cast<uint32_t*>(d_raw_) + rows * words), stream);
+        pvq_status ps = launch_peaks_frames(d_db, rows, pg, reinterpret_cast<uint8_t*>(wsb + b_mask + b_tun + b_sm), stream);
         if (ps != PVQ_OK) return ps;
-        a.raw_mask = static_cast<const uint32_t*>(d_raw_);
     }
-    const dim3 grid((n_streams_ + 3) / 4);
-    const size_t lds = (size_t)2 * npad * sizeof(float) + (size_t)a.wave_bytes * 4;
-    auto launch = [&](auto kern) -> pvq_status {
-        PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
-        return PVQ_OK;
-    };
-    pvq_status lst;
     const bool dist = a.dist > 1;
-    const int occ = dev_knob("PVQ_AB_OCC", 2);   // (developer build: A/B of the register budget)
-#ifdef PVQ_DEV_KNOBS
-#define PVQ_AB_LAUNCH(NK) \
-    (occ == 4 ? (dist ? launch(analysis_batch_preprocess<NK, true, 4>) : launch(analysis_batch_preprocess<NK, false, 4>)) \
-     : occ == 3 ? (dist ? launch(analysis_batch_preprocess<NK, true, 3>) : launch(analysis_batch_preprocess<NK, false, 3>)) \
-                : (dist ? launch(analysis_batch_preprocess<NK, true, 2>) : launch(analysis_batch_preprocess<NK, false, 2>)))
-#else
-#define PVQ_AB_LAUNCH(NK) (dist ? launch(analysis_batch_preprocess<NK, true, 2>) : launch(analysis_batch_preprocess<NK, false, 2>))
-    (void)occ;
-#endif
-    // bins per lane: the smallest instantiation that holds the frame (588 bins — the reference's default 7 x 84 — on 16 bins per lane
-    // ran at one wave per SIMD: 256 registers; on 10 it keeps two)
-    if (a.n_bins <= 256) lst = PVQ_AB_LAUNCH(4);
-    else if (a.n_bins <= 384) lst = PVQ_AB_LAUNCH(6);
-    else if (a.n_bins <= 512) lst = PVQ_AB_LAUNCH(8);
-    else if (a.n_bins <= 640) lst = PVQ_AB_LAUNCH(10);
-    else if (a.n_bins <= 768) lst = PVQ_AB_LAUNCH(12);
-    else lst = PVQ_AB_LAUNCH(16);
+    // 1. the recurrence, a wave per stream
+    {
+        const size_t lds = (size_t)ab_rec_wave_bytes(a.n_bins) * 4;
+        auto launch = [&](auto kern) -> pvq_status {
+            PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((n_streams_ + 3) / 4), dim3(256), lds, stream, a);
+            return PVQ_OK;
+        };
+        // bins per lane: the smallest instantiation that holds the frame
+        pvq_status lst = a.n_bins <= 256 ? launch(ab_recurrence<4>) : a.n_bins <= 384 ? launch(ab_recurrence<6>) : a.n_bins <= 512 ? launch(ab_recurrence<8>)
+                         : a.n_bins <= 640 ? launch(ab_recurrence<10>) : a.n_bins <= 768 ? launch(ab_recurrence<12>) : launch(ab_recurrence<16>);
+        if (lst != PVQ_OK) return lst;
+    }
+    // 2. everything that hangs on a frame's smoothed row alone, a wave per (stream, frame)
+    {
+        const size_t rows = (size_t)n_streams_ * n_frames;
+        const size_t lds = (size_t)2 * npad * sizeof(float) + (size_t)a.wave_bytes * 4;
+        const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 1u << 16);
+        auto launch = [&](auto kern) -> pvq_status {
+            PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+            return PVQ_OK;
+        };
+#define PVQ_AB_LAUNCH(NK) (dist ? launch(ab_frames<NK, true>) : launch(ab_frames<NK, false>))
+        pvq_status lst = a.n_bins <= 256 ? PVQ_AB_LAUNCH(4) : a.n_bins <= 384 ? PVQ_AB_LAUNCH(6) : a.n_bins <= 512 ? PVQ_AB_LAUNCH(8)
+                         : a.n_bins <= 640 ? PVQ_AB_LAUNCH(10) : a.n_bins <= 768 ? PVQ_AB_LAUNCH(12) : PVQ_AB_LAUNCH(16);
 #undef PVQ_AB_LAUNCH
+        if (lst != PVQ_OK) return lst;
+    }
+    // 3. the tuning inaccuracy's EMA, a thread per stream
+    hipLaunchKernelGGL(ab_tuning, dim3((n_streams_ + 255) / 256), dim3(256), 0, stream, a);
+    pvq_status lst = PVQ_OK;
     if (lst != PVQ_OK) return lst;
     PVQ_HIP(hipGetLastError());
     return PVQ_OK;

@@ -1709,7 +1709,6 @@ struct BandArgs {
     float2* out_cplx;          // optional
     unsigned* status;          // the handle's sticky flag word: bit 0 <- a live frame holds a non-finite power value
     const XTile* xmap;         // many-streams launches: per X tile, its output rows and how many of its frames exist (nullptr: tile t holds rows 64 t ...)
-    int skip_dead;             // 1: a tile none of whose frames exists (a staged buffer's gap) returns at once
     unsigned long long* stamps;   // developer knob PVQ_STAMPS_DOTS: [workgroup][8] 100 MHz clock: 0 start, 1 wave 0 done with its blocks, 2 all waves done, 3 end
 };
 
@@ -1896,7 +1895,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db(BandArgs
         rstep = xt.live_step >> 8;
         row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
         n_live = (xt.live_step & 255) - (f0 & 63);
-        if (n_live <= 0 && a.skip_dead) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
+        if (n_live <= 0) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -2017,7 +2016,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_bandd
         rstep = xt.live_step >> 8;
         row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
         n_live = (xt.live_step & 255) - (f0 & 63);
-        if (n_live <= 0 && a.skip_dead) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
+        if (n_live <= 0) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -2144,7 +2143,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void blockdft_banddots_db_bf16x3(B
         rstep = xt.live_step >> 8;
         row0 = xt.out_row0 + (long long)(f0 & 63) * rstep;
         n_live = (xt.live_step & 255) - (f0 & 63);
-        if (n_live <= 0 && a.skip_dead) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
+        if (n_live <= 0) return;   // (uniform) a staged buffer's gap frames: nothing of this tile is wanted (Vqt::batch_streams_device)
     }
     PVQ_STAMP(0);
     const int* my_list = a.list + wave * a.per_wave;
@@ -2933,9 +2932,8 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             for (auto& c : t->tile_lists)
                 if (c.bm == fused_bm && c.wide == wide_mode && c.multi == multi && c.kind == kind && c.key == key && c.slot_data == slot_data) tl = &c;
             if (!tl) {
-                static const int tl_slots = std::max(2, std::min(8, dev_knob("PVQ_TL_SLOTS", 8)));
                 tl = &t->tile_lists[t->tile_list_next];
-                t->tile_list_next = (t->tile_list_next + 1) % tl_slots;
+                t->tile_list_next = (t->tile_list_next + 1) & 7;
                 auto grp = [](const int4& e) { return e.x & 255; };
                 auto is_wide = [](const int4& e) { return ((e.x >> 8) & 1) != 0; };
                 auto seg_of = [](const int4& e) { return (int)((unsigned)e.x >> 16); };
@@ -3276,7 +3274,6 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
         da.per_wave = t->band_per_wave;
         // one run: its rows follow each other from its first output row; several: the X-tile map names every tile's rows
         da.xmap = d_xmap;
-        da.skip_dead = dev_knob("PVQ_SKIP_DEAD", 1);
         const size_t row_first = multi ? 0 : (size_t)segs[0].out_row0;
         da.out_db = d_out_db + row_first * nb;
         da.out_cplx = d_out_cplx ? reinterpret_cast<float2*>(d_out_cplx) + row_first * nb : nullptr;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer tool (GPU box): rocprofv3 kernel stats + SQ counters of analysis_batch_preprocess (one 4096-stream x 128-frame call per pass).
+# Developer tool (GPU box): rocprofv3 kernel stats + SQ counters of the AnalysisBatch kernels (ab_recurrence, ab_frames, ab_tuning and the raw-frame peaks pre-pass; one 4096-stream x 128-frame call per pass).
 # usage: scripts/pmc_analysis_batch.sh <tag> [bpo]     (bpo 36: 252 bins, 84: 588 bins; the program goes directly after `--`)
 TAG=${1:-ab}
 BPO=${2:-36}
@@ -23,7 +23,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/$TAG/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "analysis_batch" in r["Kernel_Name"]:
+        if "pvq::ab_" in r["Kernel_Name"] or "peaks_frames" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("gpurun_out/$TAG/summary.txt", "w") as out:
     for k, d in acc.items():
@@ -33,7 +33,7 @@ with open("gpurun_out/$TAG/summary.txt", "w") as out:
     st = glob.glob("gpurun_out/$TAG/stats/*/*kernel_stats.csv")
     if st:
         for i, line in enumerate(open(st[0])):
-            if i == 0 or "analysis_batch" in line:
+            if i == 0 or "pvq::ab_" in line or "peaks_frames" in line:
                 out.write(line)
 print(open("gpurun_out/$TAG/summary.txt").read())
 PY

@@ -177,7 +177,10 @@ def test_blockdft_general_hops_vs_oracle(name, hop, nf):
     # ALGO_AUTO takes this path for such a hop once the batch pays its launch floor back (a general hop's K loops are hop / 2 deep: a
     # few hundred frames are faster on the FFT path), and says beforehand which: the same bits as the forced call either way
     _set_algo(v, P.ALGO_AUTO)
-    assert v.resolve_algo(hop, 64) in (P.ALGO_FFT, P.ALGO_BLOCKDFT) and v.resolve_algo(hop, 1 << 20) == P.ALGO_BLOCKDFT
+    # (at the reference's default geometry the FFT path's per-window kernels run level with the general-hop block path — 0.035 against 0.038 us per
+    # frame at hop 1 600, profiles/r05_auto_rule.txt — and AUTO stays on the FFT path at every size; elsewhere a large batch goes to the block path)
+    assert v.resolve_algo(hop, 64) in (P.ALGO_FFT, P.ALGO_BLOCKDFT)
+    assert v.resolve_algo(hop, 1 << 20) == P.ALGO_BLOCKDFT or (name == "default_22k_588" and hop >= 1344)
     want_algo = v.resolve_algo(hop, nf)
     db2, cx2 = run_gpu(v, pcm, hop, nf, n_lead)
     assert v.last_algo() == want_algo
