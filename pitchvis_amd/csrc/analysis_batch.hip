@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
 }
 
 template <int NK, bool DIST>
-__global__ __launch_bounds__(256, 2) void ab_frames(AbArgs a) {
+__global__ __launch_bounds__(256, NK <= 6 ? 4 : (NK <= 12 ? 3 : 2)) void ab_frames(AbArgs a) {   // (latency-bound peak logic: occupancy is what makes it fast)
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
