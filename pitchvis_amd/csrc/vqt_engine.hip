@@ -682,17 +682,20 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_group(FftArgs a, int g, int 
                     if (sx + 1 >= 0 && sx + 1 < n_samples) v[u].y = pcm[sx + 1];
                 }
             }
-            float2* zt = Z + lpad(tl);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) zt[u * (T + T / 16)] = v[u];   // lpad(tl + u T) = lpad(tl) + u (T + T / 16): T is a multiple of 16
-        }
-        __syncthreads();
-        {
             // (the thread's index goes through an empty asm once per frame: left to itself the compiler hoists the 15 twiddle ADDRESSES of every
             // pass — loop-invariant 64-bit values — out of the frame loop and spills them: 380 bytes of scratch per lane, reloaded in every pass)
             int tl_ = tl;
             asm volatile("" : "+v"(tl_));
-            lds_fft_ct<N, 1, T>(Z, a.tw, a.n_tw, tl_, G.n_cols - 1);
+            // The first pass (stride 1, radix 16, no twiddles) takes item i = tl's inputs Z[tl + r N / 16] — exactly the 16 points this thread
+            // has just gathered (T = N / 16): they go through the butterfly in registers and only its outputs reach LDS.  The walk writes the
+            // gathered window to LDS, meets at a barrier and reads it back: same values, 16 LDS writes, a barrier and 16 LDS reads more.
+            // (n_cols > 1, checked by the host: with a single column the walk prunes even this pass)
+            RegFft<16>::run(v);
+            float2* zj = Z + 17 * tl_;   // lpad(16 i + r) = 17 i + r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zj[r] = v[r];
+            __syncthreads();
+            lds_fft_ct<N, 16, T>(Z, a.tw, a.n_tw, tl_, G.n_cols - 1);
         }
         // real split, in place, only for the columns the kernel reads (as in vqt_fft_frames)
         for (int c = tl; c <= N / 2; c += T) {
@@ -1271,7 +1274,7 @@ pvq_status Vqt::launch_fft_streams(const void* st_table, size_t n_st, const floa
     bool ct = ct_env && !split && !skip_env && a.n_groups >= 1 && n_frames >= 64;
     for (int g = 0; g < a.n_groups && ct; ++g) {
         const int N = dev_->h_groups[g].n_cplx;
-        ct = N >= 256 && N <= 16384 && (N & (N - 1)) == 0;
+        ct = N >= 256 && N <= 16384 && (N & (N - 1)) == 0 && dev_->h_groups[g].n_cols > 1;
     }
     if (ct) {
         constexpr size_t PART = 16384;
