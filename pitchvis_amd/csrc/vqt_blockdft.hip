@@ -2001,7 +2001,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // one register for the Re parts and one for the Im parts.  Per four columns: two 16-byte X loads and one 8-byte B load per lane
 // instead of four 8-byte loads + one, eight MFMAs as before, no swaps.  C layout: output n = lane & 15, frame 32 u + 2 (4 (lane >> 4) + r) + p.
 template <int NW, int NS, int LDB, int NU>   // LDB: row stride of the LDS tile (4 mod 16, >= bins); NU: half tiles of 32 frames per workgroup (2: a whole X tile; 1 — half a tile, 4 waves, four workgroups per CU — was measured slower: 141-150 against 121 us)
-__global__ __launch_bounds__(64 * NW, NU == 2 ? NW / 2 : NW) void blockdft_banddots4c_db(BandArgs a) {
+__global__ __launch_bounds__(64 * NW, NU == 2 || NW == 8 ? NW / 2 : NW) void blockdft_banddots4c_db(BandArgs a) {   // (four waves per SIMD)
     const int stamp_slot = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][LDB]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3312,8 +3312,27 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
             if (dots_split) {
                 da.list = t->d_band_list + (size_t)t->band_waves * t->band_per_wave;   // the 4-wave lists
                 hipLaunchKernelGGL((blockdft_banddots_db_bf16x3<1, 4>), grid, dim3(256), lds, stream, da);
-            } else {
+            } else if (dots16_env || nb > 1024 - 4) {
                 hipLaunchKernelGGL((blockdft_banddots_db<1, 8>), grid, dim3(512), lds, stream, da);
+            } else {
+                // more than 304 bins (the reference's default 588, 360, 840): the 8-bin / 16x16x4 / no-swap form on HALF tiles (32 frames x all bins
+                // per workgroup, 8 waves), its LDS row stride compiled in per class of bin counts — round 5; before, these geometries ran the
+                // 16-bin 32x32x2 form (PVQ_DOTS_16BIN=1 in the developer library)
+                da.blocks = t->d_band8;
+                da.list = t->d_band_list8;
+                da.per_wave = t->band_per_wave8;
+                da.B = t->d_band_B4;
+                const int ldb_c = nb <= 368 ? 372 : nb <= 592 ? 596 : nb <= 848 ? 852 : 1028;
+                da.ldb = ldb_c;
+                const size_t lds_c = sizeof(float) * 32 * ldb_c;
+                auto launch_c = [&](auto kern) -> pvq_status {
+                    if (lds_c > 64 * 1024) PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds_c, stream, da);
+                    return PVQ_OK;
+                };
+                pvq_status lcs = ldb_c == 372 ? launch_c(blockdft_banddots4c_db<8, BD8_NS, 372, 1>) : ldb_c == 596 ? launch_c(blockdft_banddots4c_db<8, BD8_NS, 596, 1>)
+                                 : ldb_c == 852 ? launch_c(blockdft_banddots4c_db<8, BD8_NS, 852, 1>) : launch_c(blockdft_banddots4c_db<8, BD8_NS, 1028, 1>);
+                if (lcs != PVQ_OK) return lcs;
             }
         }
         slot_end(SLOT_BLOCKDFT_DOTS, stream);
