@@ -52,6 +52,7 @@ struct AbArgs {
     const float* alpha_tab;
     const uint32_t* frame_row;
     int tab_n, tab_stride;
+    int tab_lds;   // ab_recurrence: floats of the (single) table row staged in LDS, 0: read from memory
     const float* lnf;
     int dist, min_bin, radius;
     float *smoothed, *calm, *released, *afterglow, *peakfiltered, *pitch_acc, *pitch_dev, *scene, *tuning;   // state
@@ -107,15 +108,15 @@ __device__ __forceinline__ float ab_readlane(float v, int l) { return __int_as_f
 //                   afterglow, calmness, scene calmness.  ~300 instructions per frame instead of ~1 500 (2 700 at 588 bins).
 //   ab_frames       one wave per (stream, FRAME), every frame of every stream at once: the smoothed row's peaks and everything
 //                   derived from them; leaves the frame's tuning-grid inaccuracy (100 x average) for
-//   ab_tuning       one thread per stream: the scalar EMA of pitch_analysis.rs:55-66 over the call's frames.
+//   ab_tuning       one wave per stream: the scalar EMA of pitch_analysis.rs:55-66 over the call's frames.
 // Same operations in the same order as the single kernel of rounds 3-4 (and as the host AnalysisState): the recurrence state stays
 // bit-identical to the oracle (tests/test_analysis_batch_gpu.py).  64 streams no longer mean 64 busy waves for the whole call.
 // ------------------------------------------------------------------------------------------------
 // LDS of one wave of ab_recurrence: the smoothed frame's row, the amplitude weights of the flagged bins, the compacted list of
-// flagged bins, the raw frame's peak mask words
+// flagged bins
 __host__ __device__ inline unsigned ab_rec_wave_bytes(int n_bins) {
     const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
-    return (unsigned)((sizeof(float) * 2 * npad + 2 * npad + 4 * 32 + 15) / 16 * 16);
+    return (unsigned)((sizeof(float) * 2 * npad + 2 * npad + 15) / 16 * 16);
 }
 // ... of ab_frames: the smoothed row with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into them), a
 // scratch row (the pitch rows' peak indices), the frame's continuous peaks and their accuracy / deviation (npad / 2 each), flags, the
@@ -133,12 +134,19 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x * 4 + wave;
     const int n = a.n_bins, npad = (n + 63) / 64 * 64, words = (n + 31) / 32;
-    if (s >= a.n_streams) return;   // (no workgroup barrier in this kernel: waves are independent)
-    unsigned char* base = ab_lds + (size_t)wave * ab_rec_wave_bytes(n);
+    // one frame time for the whole call (the usual case): the weights' row sits in LDS — the look-up is a link of the frame-to-frame chain
+    // (scene calmness -> horizon -> weight -> EMA -> ... -> scene calmness), and an LDS read is the shortest one
+    const float* tabL = reinterpret_cast<const float*>(ab_lds);
+    if (a.tab_lds) {
+        float* t = reinterpret_cast<float*>(ab_lds);
+        for (int i = tid; i < a.tab_lds; i += 256) t[i] = a.alpha_tab[i];
+        __syncthreads();
+    }
+    if (s >= a.n_streams) return;   // (no workgroup barrier past this point: waves are independent)
+    unsigned char* base = ab_lds + (size_t)((a.tab_lds * 4 + 15) / 16 * 16) + (size_t)wave * ab_rec_wave_bytes(n);
     float* rowA = reinterpret_cast<float*>(base);                 // the smoothed frame
     float* pw = rowA + npad;                                      // 10^(dB / 10) of the bins around a raw peak
     uint16_t* flist = reinterpret_cast<uint16_t*>(pw + npad);     // compacted list of the flagged bins
-    uint32_t* mwords = reinterpret_cast<uint32_t*>(flist + npad); // the raw frame's peak mask (32 words)
 
     float y_sm[NK], y_calm[NK], y_rel[NK], y_glow[NK];
     float bm[NK], glow_k[NK];   // analysis.rs:310-316 base * frequency_multiplier; afterglow.rs:31 decay per bin
@@ -172,33 +180,49 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
     const uint32_t* rm_s = a.raw_mask + (size_t)s * a.n_frames * words;
     const int wlane = min(lane, words - 1);
     uint32_t mw_next = rm_s[wlane];   // (lane < words <= 32 holds a word of the mask)
+    unsigned long long vmask[NK];     // the chunk's bins that lie in the frame
+#pragma unroll
+    for (int k = 0; k < NK; ++k) vmask[k] = n - 64 * k >= 64 ? ~0ull : (n - 64 * k <= 0 ? 0ull : (1ull << (n - 64 * k)) - 1ull);
 
     for (int f = 0; f < a.n_frames; ++f) {
         const size_t fr = (size_t)s * a.n_frames + f;
-        const unsigned long long dt_ns = a.frame_times ? a.frame_times[f] : a.frame_ns;
-        const float dt_s = ab_secs(dt_ns);
+        // (the frame time itself is only needed where a weight is not in the table: evaluated there)
+        auto dt_s_of = [&]() { return ab_secs(a.frame_times ? a.frame_times[f] : a.frame_ns); };
         const float* tab = a.alpha_tab ? a.alpha_tab + (size_t)(a.frame_row ? a.frame_row[f] : 0u) * a.tab_stride : nullptr;
-        const float alpha_c = tab ? tab[0] : 1.0f - ab_exp(-2.0f * dt_s / note_s);
-        const float alpha_s = tab ? tab[1] : 1.0f - ab_exp(-2.0f * dt_s / scene_s);
+        const float alpha_c = a.tab_lds ? tabL[0] : (tab ? tab[0] : 1.0f - ab_exp(-2.0f * dt_s_of() / note_s));
+        const float alpha_s = a.tab_lds ? tabL[1] : (tab ? tab[1] : 1.0f - ab_exp(-2.0f * dt_s_of() / scene_s));
         // ---- analysis.rs:295-323: per-bin EMA with a frequency- and calmness-dependent horizon; afterglow.rs:27-36
         const float cm = a.calm_min + (a.calm_max - a.calm_min) * scene;
         float alpha[NK];
         if (a.smooth_has) {   // (uniform)
-            unsigned long long hms[NK];
+            // the horizon in whole ms, trunc(base * multiplier * cm) as u64 (analysis.rs:316): it is below the table's length exactly when the
+            // float is, so the usual case needs no 64-bit conversion
+            int hidx[NK];
             bool miss = false;
+            const float tab_n_f = (float)a.tab_n;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                hms[k] = a.base_ms > 0 ? ab_trunc_u64(bm[k] * cm) : 0ull;
-                miss |= !(tab && hms[k] < (unsigned long long)a.tab_n);
+                const float xk = bm[k] * cm;
+                const bool pos = a.base_ms > 0 && xk > 0.0f;
+                const bool in = tab && (pos ? xk < tab_n_f : a.tab_n > 0);
+                hidx[k] = (pos && in) ? (int)xk : 0;
+                miss |= !in;
             }
             if (__ballot(miss) == 0) {   // the usual case: every weight is in the host's table — all NK loads in flight together
+                if (a.tab_lds) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) alpha[k] = tab[4 + (int)hms[k]];
+                    for (int k = 0; k < NK; ++k) alpha[k] = tabL[4 + hidx[k]];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) alpha[k] = tab[4 + hidx[k]];
+                }
             } else {
+                const float dt_s = dt_s_of();
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
-                    if (tab && hms[k] < (unsigned long long)a.tab_n) alpha[k] = tab[4 + (int)hms[k]];
-                    else alpha[k] = 1.0f - ab_exp(-2.0f * dt_s / ab_secs(hms[k] * 1000000ull));
+                    const unsigned long long hms = a.base_ms > 0 ? ab_trunc_u64(bm[k] * cm) : 0ull;
+                    if (tab && hms < (unsigned long long)a.tab_n) alpha[k] = tab[4 + (int)hms];
+                    else alpha[k] = 1.0f - ab_exp(-2.0f * dt_s / ab_secs(hms * 1000000ull));
                 }
             }
         }
@@ -225,11 +249,20 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
                 if (a.o.x_vqt_afterglow) a.o.x_vqt_afterglow[fr * n + bin] = g;
             }
         }
-        if (lane < 32) mwords[lane] = mw_next;
-        ab_lds_sync();
         // ---- calmness.rs:23-95: the peaks of the RAW frame (found before this kernel started: raw_mask) mark the bins "around a note":
-        //      peak p flags [max(0, p - radius), min(n, p + radius)), i.e. bin i is flagged iff one of the bins i - radius + 1 ... i + radius is a peak
-        auto raw_peak = [&](int p) { return p >= 0 && p < n && ((mwords[p >> 5] >> (p & 31)) & 1u) != 0; };
+        //      peak p flags [max(0, p - radius), min(n, p + radius)), i.e. bin i is flagged iff one of the bins i - radius + 1 ... i + radius is a peak.
+        //      On the scalar unit: the mask's words are wave-uniform, so the 64 bins of chunk k are one 64-bit word, and the flags are that word
+        //      OR-ed with its shifts by 1 ... radius down and 1 ... radius - 1 up (bits carried in from the neighbouring chunks) — which is
+        //      at once the ballot the compaction below needs.  (Round 4 read the mask bit by bit from LDS: 2 radius dependent LDS round trips per
+        //      chunk; with one wave on its SIMD nothing hides them: 1.5 of a frame's 4 us at 252 bins.)
+        unsigned long long pm[NK + 2];   // pm[k + 1]: chunk k of the raw mask; zero words on both sides
+        pm[0] = 0ull;
+        pm[NK + 1] = 0ull;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)mw_next, 2 * k), hi = (uint32_t)__builtin_amdgcn_readlane((int)mw_next, 2 * k + 1);
+            pm[k + 1] = (2 * k < words ? (unsigned long long)lo : 0ull) | (2 * k + 1 < words ? (unsigned long long)hi << 32 : 0ull);
+        }
         // amplitude weights 10^(dB / 10) of the flagged bins only (a handful per frame): compacted, one lane per flagged bin
         bool fl[NK];
         {
@@ -237,12 +270,13 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int bin = lane + 64 * k;
-                bool any = false;
-                for (int p = bin - a.radius + 1; p <= bin + a.radius; ++p) any |= raw_peak(p);
-                fl[k] = bin < n && any;
-                const unsigned long long bmk = __ballot(fl[k]);
-                if (fl[k]) flist[n_fl + __popcll(bmk & ((1ull << lane) - 1ull))] = (uint16_t)bin;
-                n_fl += __popcll(bmk);
+                unsigned long long fm = a.radius > 0 ? pm[k + 1] : 0ull;
+                for (int d = 1; d <= a.radius; ++d) fm |= (pm[k + 1] >> d) | (pm[k + 2] << (64 - d));
+                for (int d = 1; d < a.radius; ++d) fm |= (pm[k + 1] << d) | (pm[k] >> (64 - d));
+                fm &= vmask[k];   // bins of the frame
+                fl[k] = ((fm >> lane) & 1ull) != 0ull;
+                if (fl[k]) flist[n_fl + pk_rank(fm, 0)] = (uint16_t)bin;
+                n_fl += __popcll(fm);
             }
             ab_lds_sync();
             for (uint32_t idx = lane; idx < n_fl; idx += 64) {
@@ -531,22 +565,41 @@ __global__ __launch_bounds__(256, NK <= 6 ? 4 : (NK <= 12 ? 3 : 2)) void ab_fram
     }
 }
 
-// pitch_analysis.rs:55-66: smoothed_tuning_grid_inaccuracy, one thread per stream over the call's frames
+// pitch_analysis.rs:55-66: smoothed_tuning_grid_inaccuracy — a scalar EMA over the call's frames.  A wave per stream: the lanes fetch 64
+// frames' inputs and weights at once (a chunk ahead), then the recurrence runs over the lanes by readlane — two dependent operations per
+// frame.  (One thread per stream walked 1 000 frames through 1 000 exposed memory round trips: 0.42 ms beside a 2.5 ms recurrence.)
 __global__ __launch_bounds__(256) void ab_tuning(AbArgs a) {
 #pragma clang fp contract(off)
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= a.n_streams) return;
     float tuning = a.tuning[s];
     const float tuning_s = ab_secs(a.tuning_ns);
-    for (int f = 0; f < a.n_frames; ++f) {
-        const size_t fr = (size_t)s * a.n_frames + f;
-        const unsigned long long dt_ns = a.frame_times ? a.frame_times[f] : a.frame_ns;
+    const float* in_s = a.tuning_in + (size_t)s * a.n_frames;
+    auto fetch = [&](int f0, float& x, float& al) {
+        const int f = min(f0 + lane, a.n_frames - 1);
+        x = in_s[f];
         const float* tab = a.alpha_tab ? a.alpha_tab + (size_t)(a.frame_row ? a.frame_row[f] : 0u) * a.tab_stride : nullptr;
-        const float alpha_t = tab ? tab[2] : 1.0f - ab_exp(-2.0f * ab_secs(dt_ns) / tuning_s);
-        tuning = tuning + alpha_t * (a.tuning_in[fr] - tuning);
-        if (a.o.tuning_grid_inaccuracy) a.o.tuning_grid_inaccuracy[fr] = tuning;
+        al = tab ? tab[2] : 1.0f - ab_exp(-2.0f * ab_secs(a.frame_times ? a.frame_times[f] : a.frame_ns) / tuning_s);
+    };
+    float x, al;
+    fetch(0, x, al);
+    for (int f0 = 0; f0 < a.n_frames; f0 += 64) {
+        float xn, aln;
+        fetch(f0 + 64 < a.n_frames ? f0 + 64 : f0, xn, aln);
+        const int cnt = min(64, a.n_frames - f0);
+        float res = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            if (j >= cnt) break;   // (uniform)
+            tuning = tuning + ab_readlane(al, j) * (ab_readlane(x, j) - tuning);
+            res = lane == j ? tuning : res;
+        }
+        if (a.o.tuning_grid_inaccuracy && lane < cnt) a.o.tuning_grid_inaccuracy[(size_t)s * a.n_frames + f0 + lane] = res;
+        x = xn;
+        al = aln;
     }
-    a.tuning[s] = tuning;
+    if (lane == 0) a.tuning[s] = tuning;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -678,6 +731,7 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     a.alpha_tab = nullptr;
     a.frame_row = nullptr;
     a.tab_n = a.tab_stride = 0;
+    a.tab_lds = 0;
     {
         const float cmax = std::max(std::max(a.calm_min, a.calm_max), 0.0f);
         const double hmax_d = (double)a.base_ms * 1.5 * (double)cmax + 2.0;
@@ -733,6 +787,7 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
             a.alpha_tab = static_cast<const float*>(d_tab_);
             a.tab_n = (int)tab_n;
             a.tab_stride = (int)stride;
+            a.tab_lds = rows.empty() && stride <= 4096 ? (int)stride : 0;   // (16 KB of LDS at most)
             if (!rows.empty()) {
                 uint32_t* d_rows = reinterpret_cast<uint32_t*>(static_cast<char*>(d_tab_) + tab.size() * sizeof(float));
                 PVQ_HIP(hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -786,7 +841,7 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     const bool dist = a.dist > 1;
     // 1. the recurrence, a wave per stream
     {
-        const size_t lds = (size_t)ab_rec_wave_bytes(a.n_bins) * 4;
+        const size_t lds = (size_t)ab_rec_wave_bytes(a.n_bins) * 4 + (size_t)((a.tab_lds * 4 + 15) / 16 * 16);
         auto launch = [&](auto kern) -> pvq_status {
             PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((n_streams_ + 3) / 4), dim3(256), lds, stream, a);
@@ -814,7 +869,7 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
         if (lst != PVQ_OK) return lst;
     }
     // 3. the tuning inaccuracy's EMA, a thread per stream
-    hipLaunchKernelGGL(ab_tuning, dim3((n_streams_ + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ab_tuning, dim3((n_streams_ + 3) / 4), dim3(256), 0, stream, a);
     pvq_status lst = PVQ_OK;
     if (lst != PVQ_OK) return lst;
     PVQ_HIP(hipGetLastError());

@@ -249,6 +249,76 @@ __device__ __forceinline__ void pk_distance_rounds(const float* x, int n, int di
     }
 }
 
+// The same rule for dist <= 4 (every geometry up to 134 bins per octave; 84 gives 3), in registers.  Peak positions are never adjacent,
+// so within a distance below 4 a candidate has at most ONE other candidate on each side — its neighbours in the compacted (ascending)
+// list.  A lane owns list entry 64 c + lane of every chunk c; the neighbours' positions and heights are fetched once by two DPP
+// wave shifts (the wave's end lanes from the next chunk by readlane), "that neighbour is within reach and outranks me" becomes two
+// booleans, and a round is two shifts of the states and a handful of compares per chunk — no LDS traffic, no fences.  (The rounds
+// over LDS cost 4 probes x 2 reads per candidate and round: at 84 bins per octave they were a third of the peak kernel.)
+__device__ __forceinline__ int pk_from_below(int v, int lane, int carry) {   // lane l <- lane l - 1; lane 0 <- carry (uniform)
+    const int s = __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return lane == 0 ? carry : s;
+}
+__device__ __forceinline__ int pk_from_above(int v, int lane, int carry) {   // lane l <- lane l + 1; lane 63 <- carry (uniform)
+    const int s = __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    return lane == 63 ? carry : s;
+}
+template <int NC>   // chunks of 64 list entries: n_list <= 64 NC
+__device__ __forceinline__ void pk_distance_regs(const float* x, int dist, uint8_t* keep, const uint16_t* list, int n_list, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float NINF = -__builtin_huge_valf();
+    int p[NC], st[NC];
+    float h[NC];
+    const int nc = (n_list + 63) >> 6;   // chunks that hold a candidate at all (uniform): the others are skipped
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        p[c] = 1 << 20;
+        h[c] = NINF;
+        st[c] = 0;
+        if (c >= nc) continue;
+        const int k = (c << 6) + lane;
+        const bool valid = k < n_list;
+        p[c] = valid ? (int)list[valid ? k : 0] : (1 << 20);
+        h[c] = valid ? x[valid ? p[c] : 0] : NINF;
+        st[c] = valid ? 2 : 0;
+    }
+    bool L[NC], R[NC];   // the list neighbour below / above lies within reach and has the higher priority (ties: the later position)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        L[c] = R[c] = false;
+        if (c >= nc) continue;
+        const int pl = pk_from_below(p[c], lane, c > 0 ? __builtin_amdgcn_readlane(p[c > 0 ? c - 1 : 0], 63) : -(1 << 20));
+        const int pr = pk_from_above(p[c], lane, c + 1 < NC ? __builtin_amdgcn_readlane(p[c + 1 < NC ? c + 1 : c], 0) : (1 << 21));
+        const float hl = __int_as_float(pk_from_below(__float_as_int(h[c]), lane,
+                                                      c > 0 ? __builtin_amdgcn_readlane(__float_as_int(h[c > 0 ? c - 1 : 0]), 63) : __float_as_int(NINF)));
+        const float hr = __int_as_float(pk_from_above(__float_as_int(h[c]), lane,
+                                                      c + 1 < NC ? __builtin_amdgcn_readlane(__float_as_int(h[c + 1 < NC ? c + 1 : c]), 0) : __float_as_int(NINF)));
+        L[c] = (p[c] - pl < dist) & (hl > h[c]);
+        R[c] = (pr - p[c] < dist) & (hr >= h[c]);
+    }
+    for (int round = 0; round < 64 * NC; ++round) {   // (every round decides at least the highest undecided candidate)
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c >= nc) continue;
+            const int sl = pk_from_below(st[c], lane, c > 0 ? __builtin_amdgcn_readlane(st[c > 0 ? c - 1 : 0], 63) : 0);
+            const int sr = pk_from_above(st[c], lane, c + 1 < NC ? __builtin_amdgcn_readlane(st[c + 1 < NC ? c + 1 : c], 0) : 0);
+            const bool killed = (L[c] & (sl == 1)) | (R[c] & (sr == 1));
+            const bool blocked = (L[c] & (sl == 2)) | (R[c] & (sr == 2));
+            const int verdict = killed ? 0 : (blocked ? 2 : 1);
+            st[c] = st[c] == 2 ? verdict : st[c];
+            any |= st[c] == 2;
+        }
+        if (!__ballot(any)) break;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if ((c << 6) + lane < n_list) keep[p[c]] = (uint8_t)st[c];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // x: the frame's dB values in LDS (n_bins <= 64*NK floats, already visible to the whole wave);
 // scratch: peaks_scratch_bytes() bytes of LDS private to this wave.  Called by all 64 lanes.
 template <int NK>
@@ -491,7 +561,10 @@ __device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* s
     if (__ballot(plateau)) return false;
     if (DISTANCE)   // find_peaks' distance rule runs before its prominence test, once per height threshold: one evaluation at the
                     // lower threshold serves both (see peaks_wave_nk); clist is free again from step 1 on
-        pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
+    {
+        if (a.dist <= 4) pk_distance_regs<(NK + 1) / 2>(x, a.dist, keep0, clist, n_dl, lane);
+        else pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
+    }
     fmin_ = pk_wave_min(fmin_);
 
     // 1. candidates of the whole frame, compacted: the window walk then runs once per 64 candidates instead of once per 64
