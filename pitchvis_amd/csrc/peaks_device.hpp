@@ -254,7 +254,8 @@ __device__ __forceinline__ void pk_distance_rounds(const float* x, int n, int di
 // list.  A lane owns list entry 64 c + lane of every chunk c; the neighbours' positions and heights are fetched once by two DPP
 // wave shifts (the wave's end lanes from the next chunk by readlane), "that neighbour is within reach and outranks me" becomes two
 // booleans, and a round is two shifts of the states and a handful of compares per chunk — no LDS traffic, no fences.  (The rounds
-// over LDS cost 4 probes x 2 reads per candidate and round: at 84 bins per octave they were a third of the peak kernel.)
+// over LDS cost 4 probes x 2 reads per candidate and round.)  The candidate test that follows the rule (height, and the prominence the
+// frame's minimum allows at all) runs on the same registers: per list chunk, not per 64 bins of the frame.
 __device__ __forceinline__ int pk_from_below(int v, int lane, int carry) {   // lane l <- lane l - 1; lane 0 <- carry (uniform)
     const int s = __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
     return lane == 0 ? carry : s;
@@ -263,8 +264,9 @@ __device__ __forceinline__ int pk_from_above(int v, int lane, int carry) {   // 
     const int s = __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
     return lane == 63 ? carry : s;
 }
-template <int NC>   // chunks of 64 list entries: n_list <= 64 NC
-__device__ __forceinline__ void pk_distance_regs(const float* x, int dist, uint8_t* keep, const uint16_t* list, int n_list, int lane) {
+template <int NC, typename Thr>   // chunks of 64 list entries: n_list <= 64 NC
+__device__ __forceinline__ uint32_t pk_distance_regs(const float* x, int dist, const uint16_t* list, int n_list, int lane, Thr thr, float fmin, uint16_t* out,
+                                                     int dump) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float NINF = -__builtin_huge_valf();
@@ -312,11 +314,20 @@ __device__ __forceinline__ void pk_distance_regs(const float* x, int dist, uint8
         }
         if (!__ballot(any)) break;
     }
+    // the survivors that also pass the candidate test (thr(bin, H, P): the bin's height / prominence bounds; fmin: the frame's minimum)
+    // go back into the list, compacted in place (every entry sits in a register by now); the rest of the frame is never looked at again
+    uint32_t n_out = 0;
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if ((c << 6) + lane < n_list) keep[p[c]] = (uint8_t)st[c];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < NC; ++c) {
+        if (c >= nc) continue;
+        float H, P;
+        thr(p[c] < (1 << 20) ? p[c] : 0, H, P);
+        const bool pre = (st[c] == 1) & (h[c] >= H) & (h[c] - fmin >= P);
+        const unsigned long long bm = __ballot(pre);
+        out[pre ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, n_out)) : dump] = (uint16_t)p[c];
+        n_out += __popcll(bm);
+    }
+    return n_out;
 }
 
 // x: the frame's dB values in LDS (n_bins <= 64*NK floats, already visible to the whole wave);
@@ -544,7 +555,7 @@ __device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* s
             vt[k] = top ? xv : -INF;
             if (DISTANCE) {   // the distance rule's candidates (peak positions at or above the lower height threshold), compacted on the way
                 const bool c = vt[k] >= hmin;
-                keep0[i] = c ? 2 : 0;
+                if (a.dist > 4) keep0[i] = c ? 2 : 0;   // (uniform: the rounds over LDS)
                 const unsigned long long bm = __ballot(c);
                 clist[c ? pk_rank(bm, n_dl) : dump] = (uint16_t)i;
                 n_dl += __popcll(bm);
@@ -561,11 +572,23 @@ __device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* s
     if (__ballot(plateau)) return false;
     if (DISTANCE)   // find_peaks' distance rule runs before its prominence test, once per height threshold: one evaluation at the
                     // lower threshold serves both (see peaks_wave_nk); clist is free again from step 1 on
-    {
-        if (a.dist <= 4) pk_distance_regs<(NK + 1) / 2>(x, a.dist, keep0, clist, n_dl, lane);
-        else pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
-    }
+        if (a.dist > 4) pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
     fmin_ = pk_wave_min(fmin_);
+    auto thr = [&](int i, float& H, float& P) {   // analysis.rs:332-349 picks the bass or the general pair by bin
+        if (SHORT) {
+            H = thrH[i];
+            P = thrP[i];
+        } else {
+            const bool bass = i <= a.highest_bassnote;
+            H = (i >= a.min_bin) ? (bass ? a.bass_min_height : a.peak_min_height) : INF;
+            const float Pq = bass ? a.bass_min_prominence : a.peak_min_prominence;
+            P = (Pq > 0.0f) ? Pq : -INF;
+        }
+    };
+    if (DISTANCE && a.dist <= 4) {   // (uniform) rule and candidate test on the compacted list, in registers
+        n_cand_out = pk_distance_regs<(NK + 1) / 2>(x, a.dist, clist, n_dl, lane, thr, fmin_, clist, dump);
+        return true;
+    }
 
     // 1. candidates of the whole frame, compacted: the window walk then runs once per 64 candidates instead of once per 64
     //    bins (a third of the bins are local maxima, far fewer pass height / range): peak position, min_bin, height, and the
@@ -576,15 +599,7 @@ __device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* s
         if ((k << 6) >= n) break;
         const int i = (k << 6) + lane;
         float H, P;
-        if (SHORT) {
-            H = thrH[i];
-            P = thrP[i];
-        } else {
-            const bool bass = i <= a.highest_bassnote;
-            H = (i >= a.min_bin) ? (bass ? a.bass_min_height : a.peak_min_height) : INF;
-            const float Pq = bass ? a.bass_min_prominence : a.peak_min_prominence;
-            P = (Pq > 0.0f) ? Pq : -INF;
-        }
+        thr(i, H, P);
         bool pre = (vt[k] >= H) & (vt[k] - fmin_ >= P);
         if (DISTANCE) pre &= keep0[i] != 0;
         const unsigned long long bm = __ballot(pre);
