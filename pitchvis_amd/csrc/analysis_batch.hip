@@ -59,6 +59,7 @@ struct AbArgs {
     AnalysisBatchOutputs o;
     unsigned scratch_bytes;   // per-wave scratch of the peak routines: max(peaks_scratch_bytes, peaks_lean_scratch_bytes)
     unsigned wave_bytes;      // LDS bytes per wave
+    int fold_min;             // ab_recurrence: a chunk with more contributing bins than this sums them by the DPP fold (developer build: PVQ_AB_FOLD)
     int generic_peaks;        // developer build: 1 = the generic peak routine for every frame (A/B against the lean one)
     // calmness.rs:40: the peaks of the RAW frames depend on the input alone, not on the recurrence: found for all frames of all streams at
     // once by the frame kernels before this kernel starts (launch_peaks_frames), [stream][frame][words] bit masks
@@ -95,6 +96,21 @@ __device__ __forceinline__ void ab_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ float ab_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// Two running sums continued over the wave's 64 values IN LANE ORDER — ((s + v0) + v1) + ... + v63, the reference's sequential f32 sums —
+// without a readlane per element: with x' = (s + v0, v1, ..., v63), t rounds of  a[l] <- a[l - 1] + x'[l]  (one add whose first operand comes
+// through a DPP wave shift) leave the exact left fold of lanes 0 ... t in lane t, whatever the other lanes hold meanwhile.  63 dependent
+// adds per sum, the two chains interleaved.  Lane 0 adds the +0.0 an out-of-range DPP read delivers: exact for the non-negative values here.
+__device__ __forceinline__ void ab_fold2(float& sa, float& sb, float va, float vb, int lane) {
+    const float xa = lane == 0 ? sa + va : va, xb = lane == 0 ? sb + vb : vb;
+    float a = xa, b = xb;
+#pragma unroll
+    for (int t = 1; t < 64; ++t) {
+        a = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + xa;
+        b = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x138, 0xf, 0xf, true)) + xb;
+    }
+    sa = ab_readlane(a, 63);
+    sb = ab_readlane(b, 63);
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -309,11 +325,15 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
                     if (a.o.calmness) a.o.calmness[fr * n + bin] = y_calm[k];
                 }
                 unsigned long long m = __ballot(ws != 0.0f || w != 0.0f);   // (adding +0.0 to a non-negative sum changes nothing)
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    weighted_sum += ab_readlane(ws, b);
-                    weight_sum += ab_readlane(w, b);
+                if (__popcll(m) > a.fold_min) {   // (uniform) many contributing bins (a peak-rich frame): the fold over all 64 lanes is the shorter chain
+                    ab_fold2(weighted_sum, weight_sum, ws, w, lane);
+                } else {
+                    while (m) {
+                        const int b = __builtin_ctzll(m);
+                        m &= m - 1;
+                        weighted_sum += ab_readlane(ws, b);
+                        weight_sum += ab_readlane(w, b);
+                    }
                 }
             }
             if (weight_sum > 0.0f) scene = scene + alpha_s * (weighted_sum / weight_sum - scene);
@@ -811,6 +831,7 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     a.scratch_bytes = (unsigned)((std::max(peaks_scratch_bytes(a.n_bins, a.dist), peaks_lean_scratch_bytes(a.n_bins, a.dist)) + 15) / 16 * 16);
     a.wave_bytes = ab_wave_bytes(a.n_bins, a.scratch_bytes);
     a.generic_peaks = dev_knob("PVQ_AB_GENERIC", 0);
+    a.fold_min = dev_knob("PVQ_AB_FOLD", 24);
     {   // the raw frames' peaks (calmness.rs:40: the general configuration on the whole frame), every frame of every stream at once;
         // workspace of the call: the masks, the frames' tuning inputs, the smoothed rows unless the caller takes them, the frame kernels' redo flags
         const size_t rows = (size_t)n_streams_ * n_frames, words = (size_t)(a.n_bins + 31) / 32;
