@@ -835,7 +835,7 @@ __host__ __device__ inline size_t peaks_lean_lds_bytes(int n_bins, int dist, int
 
 template <int NK, bool DISTANCE, int PK_FPW>
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(NK <= 8 ? 7 : 4, 8))) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
-                                                                       uint8_t* __restrict__ redo) {
+                                                                       uint8_t* __restrict__ redo, int frame0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     constexpr int PK_FPG = PK_WAVES * PK_FPW;     // frames per workgroup and pass
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -858,7 +858,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     if (NK <= 12) {
 #pragma unroll
         for (int g = 0; g < PK_FPW; ++g) {
-            const int frame = blockIdx.x * PK_FPG + wv * PK_FPW + g;
+            const int frame = frame0 + blockIdx.x * PK_FPG + wv * PK_FPW + g;
             const float* src = db + (size_t)(frame < n_frames ? frame : 0) * n;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
@@ -877,7 +877,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         for (int i = lane; i < PK_PAD; i += 64) xs[i] = __builtin_huge_valf();
         for (int i = n + lane; i < npad + PK_PAD; i += 64) xs[PK_PAD + i] = __builtin_huge_valf();
     }
-    for (int base = blockIdx.x * PK_FPG; base < n_frames; base += gridDim.x * PK_FPG) {
+    // ONE pass per workgroup (the host launches a workgroup per PK_FPG frames; more than 2^20 workgroups' worth of frames go in further
+    // launches): written as a loop over passes, the compiler hoisted ~150 instructions of loop-invariant lane masks and addresses into
+    // a preamble and spilled them to lanes — for a loop that ran once.
+    {
+        const int base = frame0 + blockIdx.x * PK_FPG;
         if (tid == 0) *n_bass = 0;
         // 1. peak search: each wave scans its PK_FPW frames one after the other, then walks their candidates side by side
         uint32_t n_cand[PK_FPW], np[PK_FPW];
@@ -894,13 +898,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
                 float* x = rows + fi * row + PK_PAD;
                 const float* src = db + (size_t)frame * n;
                 if (NK <= 12) {
-                    const bool first = base == (int)(blockIdx.x * PK_FPG);   // (uniform) the prefetched pass
 #pragma unroll
                     for (int k = 0; k < NK; ++k) {   // the frame into its row (the tail of its last 64 stays +INF)
                         if ((k << 6) >= n) break;
                         const int i = (k << 6) + lane;
-                        const float t = first ? pre[g][k] : src[i < n ? i : n - 1];
-                        x[i] = i < n ? t : __builtin_huge_valf();
+                        x[i] = i < n ? pre[g][k] : __builtin_huge_valf();
                     }
                 } else {
                     for (int i = lane; i < n; i += 64) x[i] = src[i];
@@ -916,7 +918,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
 #pragma unroll
         for (int g = 0; g < PK_FPW; ++g)
             if (lane == 0) counts[wv * PK_FPW + g] = np[g] < a.max_peaks ? np[g] : a.max_peaks;
-        if (!a.center) continue;   // uniform: mask / count only
+        if (!a.center) return;   // uniform: mask / count only
         __syncthreads();
         // 2. enhance_peaks_continuous over the pooled peaks, one lane each; bass peaks are handed to step 3
         uint32_t pre[PK_FPG + 1];
@@ -969,7 +971,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
             pk_promote(x, a, ctr, sz);
             a.size[(size_t)(base + fi) * a.max_peaks + slot] = sz;
         }
-        __syncthreads();   // the rows, lists and counters are reused by the next pass
     }
 }
 
@@ -1866,11 +1867,14 @@ pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakPar
     const int sweep_grid = (int)std::min<size_t>(256, (n_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES));
     const int fpw = a.n_bins <= 384 ? 2 : 1;
     const size_t lds_lean = peaks_lean_lds_bytes(a.n_bins, a.dist, fpw, a.highest_bassnote);
-    const int grid_lean = (int)std::min<size_t>((n_frames + PK_WAVES * fpw - 1) / (PK_WAVES * fpw), 1u << 20);
+    const size_t fpg = (size_t)PK_WAVES * fpw;   // frames per workgroup: one pass each
     auto launch_lean = [&](auto nk_c, auto dist_c) {
         constexpr int NK = decltype(nk_c)::value;
         constexpr bool D = decltype(dist_c)::value;
-        hipLaunchKernelGGL((peaks_frames_lean<NK, D, (NK <= 6 ? 2 : 1)>), dim3(grid_lean), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo);
+        for (size_t f0 = 0; f0 < n_frames; f0 += ((size_t)1 << 20) * fpg) {
+            const int grid_lean = (int)std::min<size_t>((n_frames - f0 + fpg - 1) / fpg, (size_t)1 << 20);
+            hipLaunchKernelGGL((peaks_frames_lean<NK, D, (NK <= 6 ? 2 : 1)>), dim3(grid_lean), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo, (int)f0);
+        }
     };
     using std::integral_constant;
     if (a.dist > 1) {
