@@ -134,13 +134,18 @@ __host__ __device__ inline unsigned ab_rec_wave_bytes(int n_bins) {
     const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
     return (unsigned)((sizeof(float) * 2 * npad + 2 * npad + 15) / 16 * 16);
 }
-// ... of ab_frames: the smoothed row with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into them), a
-// scratch row (the pitch rows' peak indices), the frame's continuous peaks and their accuracy / deviation (npad / 2 each), flags, the
-// compacted bass list, the peak routines' scratch and the lean routine's peak list
+// ... of ab_frames: the smoothed row with PK_PAD samples of +INF on both sides (the lean peak routine walks off the frame into them), the
+// frame's continuous peaks (centre, size: npad / 2 each), flags, a u16 row (the compacted bass list, later the pitch rows' peak indices) and
+// a region that holds the peak routines' scratch + the lean routine's peak list while the peaks are found and refined, the peaks' pitch
+// accuracy / deviation (npad / 2 floats each) afterwards.  (Each in a place of its own, a wave took 16 KB at 588 bins: two workgroups per CU.)
+__host__ __device__ inline unsigned ab_union_bytes(int n_bins, unsigned scratch_bytes) {
+    const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
+    const unsigned a = scratch_bytes + npad /*lean peak list: npad / 2 u16*/, b = 4u * npad;
+    return a > b ? a : b;
+}
 __host__ __device__ inline unsigned ab_wave_bytes(int n_bins, unsigned scratch_bytes) {
     const unsigned npad = (unsigned)((n_bins + 63) / 64 * 64);
-    return (unsigned)((sizeof(float) * ((npad + 2 * PK_PAD) + npad + 4 * (npad / 2)) + npad /*flags*/ + 2 * npad /*bass list: u16*/ +
-                       scratch_bytes + npad /*lean peak list: npad / 2 u16*/ + 15) / 16 * 16);
+    return (unsigned)((sizeof(float) * ((npad + 2 * PK_PAD) + 2 * (npad / 2)) + npad /*flags*/ + 2 * npad /*u16 row*/ + ab_union_bytes(n_bins, scratch_bytes) + 15) / 16 * 16);
 }
 
 template <int NK>
@@ -383,15 +388,15 @@ __global__ __launch_bounds__(256, NK <= 6 ? 4 : (NK <= 12 ? 3 : 2)) void ab_fram
 
     unsigned char* base = ab_lds + (size_t)2 * npad * sizeof(float) + (size_t)wave * a.wave_bytes;
     float* rowA = reinterpret_cast<float*>(base) + PK_PAD;      // the smoothed frame (find_peaks input), +INF on both sides
-    float* rowB = rowA + npad + PK_PAD;                         // scratch row: the pitch rows' peak indices
-    float* pc_c = rowB + npad;                                  // peaks_continuous of the frame: center, size (npad / 2 each)
+    float* pc_c = rowA + npad + PK_PAD;                         // peaks_continuous of the frame: center, size (npad / 2 each)
     float* pc_s = pc_c + npad / 2;
-    float* pk_acc = pc_s + npad / 2;                            // ... and their pitch accuracy / deviation
-    float* pk_dev = pk_acc + npad / 2;
-    unsigned char* flag = reinterpret_cast<unsigned char*>(pk_dev + npad / 2);   // is-peak flags
-    uint16_t* flist = reinterpret_cast<uint16_t*>(flag + npad);                  // compacted list of the bass peaks
-    unsigned char* scratch = reinterpret_cast<unsigned char*>(flist + npad);     // the peak routines' scratch
+    unsigned char* flag = reinterpret_cast<unsigned char*>(pc_s + npad / 2);     // is-peak flags
+    uint16_t* flist = reinterpret_cast<uint16_t*>(flag + npad);                  // compacted list of the bass peaks ...
+    uint16_t* rowB = flist;                                                      // ... and, once they are promoted, the pitch rows' peak indices (1 + index, 0: none)
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(flist + npad);     // the peak routines' scratch + the lean routine's list ...
     uint16_t* plist_lean = reinterpret_cast<uint16_t*>(scratch + a.scratch_bytes);
+    float* pk_acc = reinterpret_cast<float*>(scratch);                           // ... and, once the peaks are refined, their pitch accuracy / deviation
+    float* pk_dev = pk_acc + npad / 2;
     const uint16_t* plist_gen = reinterpret_cast<const uint16_t*>(scratch + npad);   // where peaks_wave_nk leaves its list
     for (int i = lane; i < PK_PAD; i += 64) {
         rowA[-PK_PAD + i] = INF;
@@ -400,7 +405,10 @@ __global__ __launch_bounds__(256, NK <= 6 ? 4 : (NK <= 12 ? 3 : 2)) void ab_fram
     for (int i = n + lane; i < npad; i += 64) rowA[i] = INF;
     const float bpo_f = (float)a.bpo, n_f = (float)n;
 
-    for (long long fr = (long long)blockIdx.x * 4 + wave; fr < rows; fr += (long long)gridDim.x * 4) {
+    // one (stream, frame) row per wave, no loop over rows (the host launches a workgroup per 4 rows): a loop's hoisted invariants cost the
+    // lean peak kernel half its registers (vqt_engine.hip, peaks_frames_lean)
+    const long long fr = (long long)blockIdx.x * 4 + wave;
+    if (fr < rows) {
         const int s = (int)(fr / a.n_frames), f = (int)(fr - (long long)s * a.n_frames);
         float y_sm[NK];
 #pragma unroll
@@ -558,13 +566,13 @@ __global__ __launch_bounds__(256, NK <= 6 ? 4 : (NK <= 12 ? 3 : 2)) void ab_fram
         ab_wave_sync();
         for (int k = 0; k < NK; ++k) {
             const int bin = lane + 64 * k;
-            if (bin < n) rowB[bin] = 0.0f;
+            if (bin < n) rowB[bin] = 0;
         }
         ab_wave_sync();
         for (uint32_t idx = lane; idx < total; idx += 64) {
             const float rc = roundf(pc_c[idx]);
             const bool last = idx + 1 >= total || roundf(pc_c[idx + 1]) != rc;
-            if (last && rc >= 0.0f && rc < n_f) rowB[(int)rc] = (float)(idx + 1);
+            if (last && rc >= 0.0f && rc < n_f) rowB[(int)rc] = (uint16_t)(idx + 1);
         }
         ab_wave_sync();
 #pragma unroll
@@ -877,7 +885,11 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
     {
         const size_t rows = (size_t)n_streams_ * n_frames;
         const size_t lds = (size_t)2 * npad * sizeof(float) + (size_t)a.wave_bytes * 4;
-        const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 1u << 16);
+        if ((rows + 3) / 4 > 0x7fffffffull) {
+            set_last_error("analysis batch: more than 2^33 frames in one call");
+            return PVQ_ERR_INVALID_ARG;
+        }
+        const unsigned grid = (unsigned)((rows + 3) / 4);
         auto launch = [&](auto kern) -> pvq_status {
             PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);

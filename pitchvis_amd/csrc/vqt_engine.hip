@@ -643,7 +643,8 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_group(FftArgs a, int g, int 
     const int tid = threadIdx.x, tl = tid % T, fl = tid / T;
     float2* Z = reinterpret_cast<float2*>(smem) + (size_t)fl * ZLEN;
     const GroupDev G = a.groups[g];
-    for (int fg = blockIdx.x; fg * F < n_frames_here; fg += gridDim.x) {
+    {   // one group of F frames per workgroup, no loop over groups: a loop's hoisted invariants (addresses of every pass) cost registers and scratch
+        const int fg = blockIdx.x;
         const bool live = fg * F + fl < n_frames_here;
         const int gframe = frame0 + (live ? fg * F + fl : n_frames_here - 1);   // a padding frame repeats the last one and stores nothing
         const float* pcm = a.pcm;
@@ -759,7 +760,6 @@ __global__ __launch_bounds__(BLOCK, 4) void vqt_fft_group(FftArgs a, int g, int 
                 }
             }
         }
-        __syncthreads();   // the next frames' gather overwrites the spectrum columns
     }
 }
 
@@ -1289,7 +1289,7 @@ pvq_status Vqt::launch_fft_streams(const void* st_table, size_t n_st, const floa
             const size_t lds_g = (size_t)Fg * (N + N / 16 + 1) * sizeof(float2);
             auto kern = vqt_fft_group<N, BLK>;
             PVQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-            const int grid_g = (int)std::min<size_t>(((size_t)nf + Fg - 1) / Fg, 4096);
+            const int grid_g = (int)(((size_t)nf + Fg - 1) / Fg);   // a workgroup per Fg frames (the kernel makes one pass)
             hipLaunchKernelGGL(kern, dim3(grid_g), dim3(BLK), lds_g, stream, a, g, f0, nf);
             return PVQ_OK;
         };
