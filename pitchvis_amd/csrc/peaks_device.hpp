@@ -460,7 +460,7 @@ __device__ __forceinline__ bool pk_is_top(const float* x, int i, float xv) {
 // LDS scratch of the lean routine besides the frame and its peak list: candidate list (u16), 64 mask words, distance-rule states (u8)
 __host__ __device__ inline size_t peaks_lean_scratch_bytes(int n_bins, int dist) {
     const size_t n = (size_t)((n_bins + 63) / 64 * 64);
-    return n + 256 + (dist > 1 ? n /*survivors of the distance rule*/ : 0);
+    return n + 256 + (dist > 4 ? n /*survivors of the distance rule, where it runs over LDS (pk_distance_rounds)*/ : 0);
 }
 
 // plist: where the frame's peak bins go (ascending, room for npad / 2 u16; the last slot is a dump slot); n_peaks receives
@@ -575,7 +575,7 @@ __device__ __forceinline__ bool peaks_lean_scan(const float* x, unsigned char* s
         if (a.dist > 4) pk_distance_rounds(x, n, a.dist, keep0, clist, n_dl, lane);
     fmin_ = pk_wave_min(fmin_);
     auto thr = [&](int i, float& H, float& P) {   // analysis.rs:332-349 picks the bass or the general pair by bin
-        if (SHORT) {
+        if (SHORT && thrH) {   // (thrH null: no table in LDS — the list-domain test of the register distance rule reads a handful of thresholds per frame)
             H = thrH[i];
             P = thrP[i];
         } else {

@@ -830,7 +830,7 @@ __host__ __device__ inline size_t peaks_lean_lds_bytes(int n_bins, int dist, int
            + 2 * PK_FPG * npad                                   // peak lists: npad / 2 u16 per frame
            + ((2 * PK_FPG * (size_t)peaks_bass_cap(n_bins, highest_bassnote) + 3) & ~(size_t)3)   // pooled bass list: u16 (frame << 10 | slot)
            + 2 * PK_FPG * sizeof(uint32_t) + 16                  // per-frame peak counts, bass counter
-           + (n_bins <= 768 ? 2 * npad * sizeof(float) : 0);     // thresholds of the candidate test (NK <= 12)
+           + (n_bins <= 768 && !(dist > 1 && dist <= 4) ? 2 * npad * sizeof(float) : 0);   // thresholds of the candidate test (NK <= 12; not with the register distance rule)
 }
 
 template <int NK, bool DISTANCE, int PK_FPW>
@@ -867,7 +867,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
             }
         }
     }
-    if (NK <= 12) {   // (beyond 768 bins peaks_lean_scan computes them on the fly)
+    const bool thr_lds = NK <= 12 && !(DISTANCE && a.dist <= 4);   // (beyond 768 bins, and on the list of the register distance rule, peaks_lean_scan computes them on the fly)
+    if (thr_lds) {
         peaks_lean_thresholds(thrH, thrP, a, tid, PK_WAVES * 64);
         __syncthreads();
     }
@@ -909,7 +910,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                done[g] = peaks_lean_scan<NK, DISTANCE>(x, scratch0 + fi * sb, thrH, thrP, n_cand[g], a, lane);
+                done[g] = peaks_lean_scan<NK, DISTANCE>(x, scratch0 + fi * sb, thr_lds ? thrH : nullptr, thrP, n_cand[g], a, lane);
                 if (lane == 0) redo[frame] = done[g] ? 0 : 1;   // the generic kernel produces that frame's outputs, the continuous ones included
             }
         }
