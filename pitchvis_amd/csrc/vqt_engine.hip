@@ -833,12 +833,13 @@ __host__ __device__ inline size_t peaks_lean_lds_bytes(int n_bins, int dist, int
            + (n_bins <= 768 && !(dist > 1 && dist <= 4) ? 2 * npad * sizeof(float) : 0);   // thresholds of the candidate test (NK <= 12; not with the register distance rule)
 }
 
-template <int NK, bool DISTANCE, int PK_FPW>
+template <int NK, bool DISTANCE, int PK_FPW, bool DENSE>   // DENSE: 64 (NK - 1) < n_bins <= 64 NK (the host's promise): every chunk test but the last one's folds away
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(NK <= 8 ? 7 : 4, 8))) void peaks_frames_lean(const float* __restrict__ db, int n_frames, PeakParamsDev a,
                                                                        uint8_t* __restrict__ redo, int frame0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     constexpr int PK_FPG = PK_WAVES * PK_FPW;     // frames per workgroup and pass
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if constexpr (DENSE) __builtin_assume(a.n_bins > 64 * (NK - 1) && a.n_bins <= 64 * NK);
     const int n = a.n_bins;
     const int npad = (n + 63) / 64 * 64;
     const int row = npad + 2 * PK_PAD;
@@ -1874,7 +1875,10 @@ pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakPar
         constexpr bool D = decltype(dist_c)::value;
         for (size_t f0 = 0; f0 < n_frames; f0 += ((size_t)1 << 20) * fpg) {
             const int grid_lean = (int)std::min<size_t>((n_frames - f0 + fpg - 1) / fpg, (size_t)1 << 20);
-            hipLaunchKernelGGL((peaks_frames_lean<NK, D, (NK <= 6 ? 2 : 1)>), dim3(grid_lean), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo, (int)f0);
+            if (a.n_bins > 64 * (NK - 1))
+                hipLaunchKernelGGL((peaks_frames_lean<NK, D, (NK <= 6 ? 2 : 1), true>), dim3(grid_lean), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo, (int)f0);
+            else
+                hipLaunchKernelGGL((peaks_frames_lean<NK, D, (NK <= 6 ? 2 : 1), false>), dim3(grid_lean), dim3(PK_WAVES * 64), lds_lean, stream, d_db, (int)n_frames, a, redo, (int)f0);
         }
     };
     using std::integral_constant;
