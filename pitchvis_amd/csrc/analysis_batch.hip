@@ -148,12 +148,13 @@ __host__ __device__ inline unsigned ab_wave_bytes(int n_bins, unsigned scratch_b
     return (unsigned)((sizeof(float) * ((npad + 2 * PK_PAD) + 2 * (npad / 2)) + npad /*flags*/ + 2 * npad /*u16 row*/ + ab_union_bytes(n_bins, scratch_bytes) + 15) / 16 * 16);
 }
 
-template <int NK>
+template <int NK, bool DENSE>   // DENSE: 64 (NK - 1) < n_bins <= 64 NK (the host's promise: the chunk tests and the padded length fold away)
 __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recurrence(AbArgs a) {   // (the per-bin state lives in registers: 7 NK values per lane)
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x * 4 + wave;
+    if constexpr (DENSE) __builtin_assume(a.n_bins > 64 * (NK - 1) && a.n_bins <= 64 * NK);
     const int n = a.n_bins, npad = (n + 63) / 64 * 64, words = (n + 31) / 32;
     // one frame time for the whole call (the usual case): the weights' row sits in LDS — the look-up is a link of the frame-to-frame chain
     // (scene calmness -> horizon -> weight -> EMA -> ... -> scene calmness), and an LDS read is the shortest one
@@ -362,11 +363,12 @@ __global__ __launch_bounds__(256, NK <= 4 ? 4 : (NK <= 8 ? 3 : 2)) void ab_recur
     if (lane == 0) a.scene[s] = scene;
 }
 
-template <int NK, bool DIST>
+template <int NK, bool DIST, bool DENSE>
 __global__ __launch_bounds__(256, NK <= 6 ? 4 : (NK <= 12 ? 3 : 2)) void ab_frames(AbArgs a) {   // (latency-bound peak logic: occupancy is what makes it fast)
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (DENSE) __builtin_assume(a.n_bins > 64 * (NK - 1) && a.n_bins <= 64 * NK);
     const int n = a.n_bins, npad = (n + 63) / 64 * 64, words = (n + 31) / 32;
     const float INF = __builtin_huge_valf();
     const long long rows = (long long)a.n_streams * a.n_frames;
@@ -877,8 +879,10 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
             return PVQ_OK;
         };
         // bins per lane: the smallest instantiation that holds the frame
-        pvq_status lst = a.n_bins <= 256 ? launch(ab_recurrence<4>) : a.n_bins <= 384 ? launch(ab_recurrence<6>) : a.n_bins <= 512 ? launch(ab_recurrence<8>)
-                         : a.n_bins <= 640 ? launch(ab_recurrence<10>) : a.n_bins <= 768 ? launch(ab_recurrence<12>) : launch(ab_recurrence<16>);
+#define PVQ_AB_REC(NK) (a.n_bins > 64 * (NK - 1) ? launch(ab_recurrence<NK, true>) : launch(ab_recurrence<NK, false>))
+        pvq_status lst = a.n_bins <= 256 ? PVQ_AB_REC(4) : a.n_bins <= 384 ? PVQ_AB_REC(6) : a.n_bins <= 512 ? PVQ_AB_REC(8)
+                         : a.n_bins <= 640 ? PVQ_AB_REC(10) : a.n_bins <= 768 ? PVQ_AB_REC(12) : PVQ_AB_REC(16);
+#undef PVQ_AB_REC
         if (lst != PVQ_OK) return lst;
     }
     // 2. everything that hangs on a frame's smoothed row alone, a wave per (stream, frame)
@@ -895,7 +899,8 @@ pvq_status AnalysisBatch::preprocess_device(const float* d_db, size_t n_frames, 
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
             return PVQ_OK;
         };
-#define PVQ_AB_LAUNCH(NK) (dist ? launch(ab_frames<NK, true>) : launch(ab_frames<NK, false>))
+#define PVQ_AB_LAUNCH(NK) (a.n_bins > 64 * (NK - 1) ? (dist ? launch(ab_frames<NK, true, true>) : launch(ab_frames<NK, false, true>)) \
+                                                   : (dist ? launch(ab_frames<NK, true, false>) : launch(ab_frames<NK, false, false>)))
         pvq_status lst = a.n_bins <= 256 ? PVQ_AB_LAUNCH(4) : a.n_bins <= 384 ? PVQ_AB_LAUNCH(6) : a.n_bins <= 512 ? PVQ_AB_LAUNCH(8)
                          : a.n_bins <= 640 ? PVQ_AB_LAUNCH(10) : a.n_bins <= 768 ? PVQ_AB_LAUNCH(12) : PVQ_AB_LAUNCH(16);
 #undef PVQ_AB_LAUNCH
