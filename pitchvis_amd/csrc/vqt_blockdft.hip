@@ -920,8 +920,9 @@ __device__ __forceinline__ void fused_f32_narrow_tile(const GemmTreeArgs& a, con
         if (lane == 0) atomicMax(ends + 2, wall_clock64()); \
         if (tid == 0) ends[0] = t_entry; \
     }
-template <int BM>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 (wide tiles: 64) complex columns
-__global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) {   // 4 waves per SIMD = two 512-thread (four 256-thread) workgroups per CU: at most 128 registers
+template <int BM, int KFIX = 0>   // rows of hop blocks per tile; 2 * BM threads = BM / 32 waves of 32 rows x 32 (wide tiles: 64) complex columns; KFIX: the hop, where the instantiation knows it (0: any)
+__global__ __launch_bounds__(2 * BM, 4) void blockdft_gemm_tree(GemmTreeArgs a) {
+    if constexpr (KFIX != 0) __builtin_assume(a.K == KFIX);   // 4 waves per SIMD = two 512-thread (four 256-thread) workgroups per CU: at most 128 registers
     constexpr bool WIDE = BM == 256;                   // (the 128-row form, a test shape, takes narrow tiles only)
     constexpr int B_FLOATS = (WIDE ? 2 : 1) * FR_KC * FT_BN;   // a wide tile's two slices of E
     constexpr int P_FLOATS = (BM + 15) * FT_LDP * 2;   // 15 spare rows: the register tree levels read their halo without a range check
@@ -2002,6 +2003,13 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // instead of four 8-byte loads + one, eight MFMAs as before, no swaps.  C layout: output n = lane & 15, frame 32 u + 2 (4 (lane >> 4) + r) + p.
 template <int NW, int NS, int LDB, int NU>   // LDB: row stride of the LDS tile (4 mod 16, >= bins); NU: half tiles of 32 frames per workgroup (2: a whole X tile; 1 — half a tile, 4 waves, four workgroups per CU — was measured slower: 141-150 against 121 us)
 __global__ __launch_bounds__(64 * NW, NU == 2 || NW == 8 ? NW / 2 : NW) void blockdft_banddots4c_db(BandArgs a) {   // (four waves per SIMD)
+    // the bin counts an LDS row stride serves (the host's choice of the instantiation): the finish's other size classes fold away
+    if constexpr (LDB == 260) __builtin_assume(a.n_bins <= 256);
+    else if constexpr (LDB == 308) __builtin_assume(a.n_bins > 256 && a.n_bins <= 304);
+    else if constexpr (LDB == 372) __builtin_assume(a.n_bins > 304 && a.n_bins <= 368);
+    else if constexpr (LDB == 596) __builtin_assume(a.n_bins > 368 && a.n_bins <= 592);
+    else if constexpr (LDB == 852) __builtin_assume(a.n_bins > 592 && a.n_bins <= 848);
+    else if constexpr (LDB == 1028) __builtin_assume(a.n_bins > 848 && a.n_bins <= 1024);
     const int stamp_slot = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) float dbs[];   // [64][LDB]: |x_vqt|^2, then dB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3180,6 +3188,8 @@ pvq_status Vqt::launch_blockdft_streams(const StreamIn* st, size_t n_st, size_t 
                 hipLaunchKernelGGL(blockdft_gemm_tree_bf16x3<256>, dim3(off), dim3(512), 0, stream, fa);
             else if (tree3)
                 hipLaunchKernelGGL(blockdft_gemm_tree3<256>, dim3(off), dim3(512), 0, stream, fa);
+            else if (fused_bm == 256 && fa.K == 256 && dev_knob("PVQ_KFIX", 1))   // the instantiations that know the hop: 2 % fewer cycles (its strides and trip counts fold)
+                hipLaunchKernelGGL((blockdft_gemm_tree<256, 256>), dim3(off), dim3(512), dyn_lds_env, stream, fa);
             else if (fused_bm == 256)
                 hipLaunchKernelGGL(blockdft_gemm_tree<256>, dim3(off), dim3(512), dyn_lds_env, stream, fa);
             else
