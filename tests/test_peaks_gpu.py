@@ -74,6 +74,28 @@ def test_random_ties_two_and_three_sample_plateaus(name):
         assert count[f] == wp.size
 
 
+@pytest.mark.parametrize("bpo,octaves", [(120, 5), (144, 4), (60, 7)])
+def test_distance_rule_at_other_distances(bpo, octaves):
+    """min_distance = round(0.4 bpo / 12): 4 at 120 bins per octave (the register form of the rule, pk_distance_regs: at most one other candidate within reach
+    on each side), 5 at 144 (two within reach: the rounds over LDS, pk_distance_rounds), 2 at 60; peak sets against the oracle on random frames with and without ties"""
+    from helpers import geom_pair
+    pp, op = geom_pair(48000.0, 55.0, octaves, bpo)
+    v = P.Vqt.new(pp, 0)
+    n = v.n_bins
+    rng = np.random.default_rng(bpo)
+    frames = np.abs(rng.normal(0, 9, (200, n))).astype(np.float32)
+    frames[100:] = np.round(frames[100:] * 2.0) / 2.0     # a coarse grid: many exact ties between neighbouring candidates (the tie rule: the later position wins)
+    for f in range(0, 200, 5):
+        i = int(rng.integers(4, n - 12))
+        frames[f, i:i + 9:2] = 30.0 + np.arange(5, dtype=np.float32) * (0.0 if f % 10 else 0.5)   # a chain of candidates two bins apart
+        frames[f, i + 1:i + 8:2] = 1.0
+    mask, count, center, size = v.analyze_batch(frames, max_peaks=n)
+    for f in range(frames.shape[0]):
+        wp, wce, wsz = O.analyze_frame(frames[f], op.min_freq, op.octaves, op.buckets_per_octave)
+        assert np.array_equal(mask_to_indices(mask[f], n), wp), (bpo, f)
+        assert count[f] == wp.size
+
+
 def test_crafted_plateaus_edges_and_split():
     pp, op = get_geom("bench_48k_252")
     v = P.Vqt.new(pp, 0)
