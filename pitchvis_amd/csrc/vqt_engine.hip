@@ -1855,7 +1855,7 @@ pvq_status Vqt::launch_peaks_kernel(const float* d_db, size_t n_frames, const Pe
 pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakParamsDev& a, uint8_t* redo, hipStream_t stream) {
     const int npad = (a.n_bins + 63) / 64 * 64;
     const size_t lds_gen = PK_WAVES * (sizeof(float) * npad + peaks_scratch_bytes(a.n_bins, a.dist));
-    // bins per lane: 4 (<= 256 bins), 8 (<= 512), 12 (<= 768) or 16 (<= 1024); the lean kernel also has 6 (<= 384) and 10 (<= 640)
+    // bins per lane: 4 (<= 256 bins), 8 (<= 512), 12 (<= 768) or 16 (<= 1024); the lean kernel also has 5 (<= 320), 6 (<= 384) and 10 (<= 640)
     auto launch_generic = [&](int g, const uint8_t* flags) {
         if (a.n_bins <= 256)
             hipLaunchKernelGGL(peaks_frames_generic<4>, dim3(g), dim3(PK_WAVES * 64), lds_gen, stream, d_db, (int)n_frames, a, flags);
@@ -1884,6 +1884,7 @@ pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakPar
     using std::integral_constant;
     if (a.dist > 1) {
         if (a.n_bins <= 256) launch_lean(integral_constant<int, 4>{}, std::true_type{});
+        else if (a.n_bins <= 320) launch_lean(integral_constant<int, 5>{}, std::true_type{});
         else if (a.n_bins <= 384) launch_lean(integral_constant<int, 6>{}, std::true_type{});
         else if (a.n_bins <= 512) launch_lean(integral_constant<int, 8>{}, std::true_type{});
         else if (a.n_bins <= 640) launch_lean(integral_constant<int, 10>{}, std::true_type{});   // (588 bins = 7 x 84: the reference's default geometry)
@@ -1891,6 +1892,7 @@ pvq_status launch_peaks_frames(const float* d_db, size_t n_frames, const PeakPar
         else launch_lean(integral_constant<int, 16>{}, std::true_type{});
     } else {
         if (a.n_bins <= 256) launch_lean(integral_constant<int, 4>{}, std::false_type{});
+        else if (a.n_bins <= 320) launch_lean(integral_constant<int, 5>{}, std::false_type{});   // (288 bins = 8 x 36: BASELINE configs[2])
         else if (a.n_bins <= 384) launch_lean(integral_constant<int, 6>{}, std::false_type{});
         else if (a.n_bins <= 512) launch_lean(integral_constant<int, 8>{}, std::false_type{});
         else if (a.n_bins <= 640) launch_lean(integral_constant<int, 10>{}, std::false_type{});

@@ -30,7 +30,7 @@ def _frames(op, nf, seed, hop=2048):
     return ov.calculate_batch(pcm.astype(np.float32), hop, nf, n_lead=30000)
 
 
-@pytest.mark.parametrize("name", ["bench_48k_252", "default_22k_588", "hires_96k_360", "hires_96k_840", "serial_22k_180"])
+@pytest.mark.parametrize("name", ["bench_48k_252", "bench_48k_288", "default_22k_588", "hires_96k_360", "hires_96k_840", "serial_22k_180"])
 def test_peaks_bit_identical_on_same_frames(name):
     pp, op = get_geom(name)
     v = P.Vqt.new(pp, 0)
@@ -47,7 +47,7 @@ def test_peaks_bit_identical_on_same_frames(name):
         assert (np.abs(size[f, :k] - wsz) <= 2e-3 + 40.0 * ctol).all()  # up to ~40 dB/bin slope in random frames
 
 
-@pytest.mark.parametrize("name", ["bench_48k_252", "default_22k_588", "hires_96k_840"])
+@pytest.mark.parametrize("name", ["bench_48k_252", "bench_48k_288", "default_22k_588", "hires_96k_840"])
 def test_random_ties_two_and_three_sample_plateaus(name):
     """Exact ties of neighbouring bins (the lean kernel takes two-sample plateaus itself, longer ones go to the
     generic kernel): random frames with ties copied in at random places, at the frame edges and next to each other."""
