@@ -2006,7 +2006,7 @@ __global__ __launch_bounds__(64 * NW, NU == 2 || NW == 8 ? NW / 2 : NW) void blo
     // the bin counts an LDS row stride serves (the host's choice of the instantiation): the finish's other size classes fold away
     if constexpr (LDB == 260) __builtin_assume(a.n_bins <= 256);
     else if constexpr (LDB == 308) __builtin_assume(a.n_bins > 256 && a.n_bins <= 304);
-    else if constexpr (LDB == 372) __builtin_assume(a.n_bins > 304 && a.n_bins <= 368);
+    else if constexpr (LDB == 372) __builtin_assume(a.n_bins > 256 && a.n_bins <= 368);   // (257 ... 304 bins come here with the developer knob PVQ_DOTS_F32 behind the split-bf16 GEMM)
     else if constexpr (LDB == 596) __builtin_assume(a.n_bins > 368 && a.n_bins <= 592);
     else if constexpr (LDB == 852) __builtin_assume(a.n_bins > 592 && a.n_bins <= 848);
     else if constexpr (LDB == 1028) __builtin_assume(a.n_bins > 848 && a.n_bins <= 1024);
